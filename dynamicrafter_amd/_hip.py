@@ -1,0 +1,105 @@
+"""ctypes binding of libdcrafter_hip.so (C ABI declared in include/dcrafter_hip.h).
+
+The product path has no fallback: if the shared library is missing or a symbol cannot be resolved, importing
+this module's `lib()` raises. PyTorch is used only for device memory and the current-stream handle.
+"""
+import ctypes as C
+import os
+import threading
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libdcrafter_hip.so")
+
+DC_GEMM_OUT_F32 = 1
+DC_GEMM_GEGLU = 2
+
+
+class DcGemmParams(C.Structure):
+    _fields_ = [
+        ("A", C.c_void_p), ("W", C.c_void_p), ("C", C.c_void_p), ("bias", C.c_void_p),
+        ("rowvec", C.c_void_p), ("residual", C.c_void_p),
+        ("lda", C.c_int), ("ldc", C.c_int), ("ldr", C.c_int), ("rowvec_ld", C.c_int),
+        ("rows_per_vec", C.c_int),
+        ("M", C.c_int), ("N", C.c_int), ("K", C.c_int), ("n_pad", C.c_int),
+        ("mode", C.c_int), ("Cin", C.c_int),
+        ("IH", C.c_int), ("IW", C.c_int), ("OH", C.c_int), ("OW", C.c_int),
+        ("stride", C.c_int), ("pad", C.c_int), ("ups", C.c_int),
+        ("T", C.c_int), ("HW", C.c_int),
+        ("flags", C.c_int), ("alpha", C.c_float),
+    ]
+
+
+class DcDdimParams(C.Structure):
+    _fields_ = [
+        ("a_t", C.c_void_p), ("a_prev", C.c_void_p), ("sigma_t", C.c_void_p), ("sqrt_one_minus_at", C.c_void_p),
+        ("sqrt_acp_t", C.c_void_p), ("sqrt_1macp_t", C.c_void_p), ("scale_ratio", C.c_void_p),
+        ("step_index", C.c_void_p),
+        ("index", C.c_int), ("v_param", C.c_int),
+        ("cfg_scale", C.c_float), ("cfg_img", C.c_float), ("guidance_rescale", C.c_float),
+        ("temperature", C.c_float),
+    ]
+
+
+# name -> (restype, argtypes); must list every symbol include/dcrafter_hip.h declares
+_P, _I, _F, _L = C.c_void_p, C.c_int, C.c_float, C.c_int64
+SIGNATURES = {
+    "dc_gemm_conv": (_I, [C.POINTER(DcGemmParams), _P]),
+    "dc_groupnorm": (_I, [_P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _F, _I, _P, _P]),
+    "dc_groupnorm_workspace_bytes": (_L, [_I, _I, _I]),
+    "dc_layernorm": (_I, [_P, _I, _P, _I, _P, _P, _I, _I, _F, _P]),
+    "dc_flash_attn_d64": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _L, _L, _F, _I, _F, _P]),
+    "dc_temporal_attn_d64": (_I, [_P, _I, _P, _I, _I, _I, _I, _I, _F, _P]),
+    "dc_gemv_small": (_I, [_P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "dc_timestep_embedding": (_I, [_P, _P, _I, _P, _I, _I, _F, _P]),
+    "dc_pack_latent": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "dc_nchw_to_rows": (_I, [_P, _P, _I, _I, _I, _I, _F, _P]),
+    "dc_rows_to_nchw": (_I, [_P, _I, _I, _P, _I, _I, _I, _F, _P]),
+    "dc_copy2d": (_I, [_P, _I, _P, _I, _I, _I, _P]),
+    "dc_build_context": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
+    "dc_softmax_rows": (_I, [_P, _I, _P, _I, _I, _I, _P]),
+    "dc_add_rows": (_I, [_P, _I, _P, _I, _P, _I, _I, _I, _P]),
+    "dc_vae_sample": (_I, [_P, _I, _P, _P, _I, _I, _I, _F, _P]),
+    "dc_ddim_step": (_I, [C.POINTER(DcDdimParams), _P, _P, _P, _I, _P, _P, _P, _P, _I, _I, _I, _P, _P]),
+    "dc_advance_counter": (_I, [_P, _P]),
+    "dc_stream_create": (_I, [C.POINTER(_P)]),
+    "dc_stream_destroy": (_I, [_P]),
+    "dc_stream_sync": (_I, [_P]),
+    "dc_graph_begin_capture": (_I, [_P]),
+    "dc_graph_end_capture": (_I, [_P, C.POINTER(_P)]),
+    "dc_graph_launch": (_I, [_P, _P]),
+    "dc_graph_destroy": (_I, [_P]),
+    "dc_event_create": (_I, [C.POINTER(_P)]),
+    "dc_event_record": (_I, [_P, _P]),
+    "dc_event_elapsed_ms": (_I, [_P, _P, C.POINTER(_F)]),
+    "dc_event_destroy": (_I, [_P]),
+    "dc_version": (C.c_char_p, []),
+}
+
+_lib = None
+_lock = threading.Lock()
+
+
+def lib():
+    """Load (once) and return the C-ABI library. Raises if it is absent: there is no CPU path."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is None:
+            if not os.path.exists(LIB_PATH):
+                raise RuntimeError(
+                    f"{LIB_PATH} not found: build it with dynamicrafter_amd/csrc/build.sh "
+                    "(or __graft_entry__.build()); the HIP extension is mandatory, there is no fallback")
+            l = C.CDLL(LIB_PATH)
+            for name, (res, args) in SIGNATURES.items():
+                fn = getattr(l, name)  # AttributeError if the symbol is missing
+                fn.restype = res
+                fn.argtypes = args
+            _lib = l
+    return _lib
+
+
+def check(code, what):
+    if code != 0:
+        raise RuntimeError(f"{what} failed with code {code}"
+                           + (" (DC_ERR_SHAPE)" if code == -1 else " (DC_ERR_ARG)" if code == -2 else " (hipError_t)"))

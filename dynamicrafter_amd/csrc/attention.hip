@@ -1,0 +1,338 @@
+// Attention kernels for gfx950, head_dim 64.
+//
+// dc_flash_attn_d64: softmax(q k^T * scale) v without materialising scores (spatial self-attention N = L up to
+//   9216 tokens per frame; text (L=77) and image (L=16) cross-attention with the o += s*result epilogue).
+//   reference: CrossAttention.forward lvdm/modules/attention.py:101-142.
+//   Structure: workgroup = 4 waves x 32 query rows; KV tiles of 64 keys staged global -> registers -> LDS
+//   (double-buffered, next tile's loads issued before the MFMA block). Scores are computed transposed,
+//   S^T = K Q^T with v_mfma_f32_32x32x16_bf16, so a lane owns one query row: the softmax max/sum are per-lane
+//   scalars and the S^T accumulator is, after exp2 and bf16 packing, directly the B operand of O^T += V^T P^T
+//   (k order permuted as the accumulator layout dictates; V^T fragments come from ds_read_b64_tr_b16).
+//
+// dc_temporal_attn_d64: attention across the T<=16 frames of one spatial position (one wave per
+//   (clip, position, head)); reference: TemporalTransformer.forward attention.py:365-412 -> CrossAttention :81-144.
+#include "dc_common.h"
+#include "dcrafter_hip.h"
+
+namespace {
+
+typedef __attribute__((address_space(3))) bf16x4_t lds_bf16x4_t;
+
+__device__ __forceinline__ int k_lds_off(int row, int chunk) {
+    return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4);
+}
+constexpr int V_LD = 192;  // bytes per V row in LDS: 4 consecutive rows land on 4 distinct 64-byte bank quarters
+
+constexpr int FA_BQ = 128;   // query rows per workgroup
+constexpr int FA_BKV = 64;   // keys per tile
+constexpr int FA_KBYTES = FA_BKV * 128;
+constexpr int FA_VBYTES = FA_BKV * V_LD;
+constexpr int FA_STAGE = FA_KBYTES + FA_VBYTES;
+
+__global__ __launch_bounds__(256) void flash_attn_d64_kernel(
+    const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v, bf16_t* __restrict__ o,
+    int ldq, int ldk, int ldv, int ldo, int heads, int Lq, int Lk, int64_t q_bstride, int64_t kv_bstride,
+    float c /* scale*log2(e) */, int accumulate, float acc_scale, int q_tiles) {
+    __shared__ __attribute__((aligned(16))) char smem[2 * FA_STAGE];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fr = lane & 31, fh = lane >> 5;
+
+    const int nwg = gridDim.x;
+    const int id = xcd_remap(blockIdx.x, nwg);
+    const int qt = id % q_tiles;
+    const int bh = id / q_tiles;
+    const int head = bh % heads;
+    const int b = bh / heads;
+
+    const bf16_t* qb = q + (size_t)b * q_bstride * ldq + head * 64;
+    const bf16_t* kb = k + (size_t)b * kv_bstride * ldk + head * 64;
+    const bf16_t* vb = v + (size_t)b * kv_bstride * ldv + head * 64;
+    bf16_t* ob = o + (size_t)b * q_bstride * ldo + head * 64;
+
+    // ---- Q fragments (B operand): lane (r, h) holds Q[i0 + r][16kk + 8h .. +7]
+    const int qrow = qt * FA_BQ + wave * 32 + fr;
+    const int qrow_c = qrow < Lq ? qrow : Lq - 1;
+    bf16x8_t qf[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk)
+        qf[kk] = *reinterpret_cast<const bf16x8_t*>(qb + (size_t)qrow_c * ldq + kk * 16 + fh * 8);
+
+    // ---- staging coordinates: 64 rows x 8 chunks per tensor, 2 rows per thread
+    const int chunk = tid & 7, srow = tid >> 3;
+    uint4 kreg[2], vreg[2];
+    auto load_tile = [&](int t) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int j = t * FA_BKV + srow + 32 * i;
+            if (j < Lk) {
+                kreg[i] = *reinterpret_cast<const uint4*>(kb + (size_t)j * ldk + chunk * 8);
+                vreg[i] = *reinterpret_cast<const uint4*>(vb + (size_t)j * ldv + chunk * 8);
+            } else {
+                kreg[i] = make_uint4(0, 0, 0, 0);
+                vreg[i] = make_uint4(0, 0, 0, 0);
+            }
+        }
+    };
+    auto store_tile = [&](int buf) {
+        char* sk = smem + buf * FA_STAGE;
+        char* sv = sk + FA_KBYTES;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int r = srow + 32 * i;
+            *reinterpret_cast<uint4*>(sk + k_lds_off(r, chunk)) = kreg[i];
+            *reinterpret_cast<uint4*>(sv + r * V_LD + chunk * 16) = vreg[i];
+        }
+    };
+
+    f32x16_t oacc[2];
+#pragma unroll
+    for (int d = 0; d < 2; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[d][r] = 0.f;
+    float m_run = -1e30f, l_run = 0.f;
+
+    const int nt = (Lk + FA_BKV - 1) / FA_BKV;
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+
+    // per-lane byte offset of the transposed V read inside a 4-row block: lane i of a 16-lane group supplies
+    // row (i>>2), columns 4*(i&3).. of the 16-column block ((lane>>4)&1)
+    const int li = lane & 15;
+    const int tr_off = (li >> 2) * V_LD + (((lane >> 4) & 1) * 16 + (li & 3) * 4) * 2;
+
+    for (int t = 0; t < nt; ++t) {
+        const int buf = t & 1;
+        if (t + 1 < nt) load_tile(t + 1);
+        const char* sk = smem + buf * FA_STAGE;
+        const char* sv = sk + FA_KBYTES;
+
+        // S^T[jb] = K[jb] Q^T
+        f32x16_t s[2];
+#pragma unroll
+        for (int jb = 0; jb < 2; ++jb) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[jb][r] = 0.f;
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                const bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(sk + k_lds_off(jb * 32 + fr, kk * 2 + fh));
+                s[jb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[kk], s[jb], 0, 0, 0);
+            }
+        }
+        // mask keys beyond Lk (last tile only)
+        if ((t + 1) * FA_BKV > Lk) {
+#pragma unroll
+            for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int j = t * FA_BKV + jb * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+                    if (j >= Lk) s[jb][r] = -1e30f;
+                }
+        }
+        // online softmax: this lane owns query row `fr`; its partner (lane ^ 32) holds the other keys
+        float mx = s[0][0];
+#pragma unroll
+        for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[jb][r]);
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m_run, mx);
+        const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
+        const float mc = m_new * c;
+        m_run = m_new;
+        float psum = 0.f;
+#pragma unroll
+        for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float p = __builtin_amdgcn_exp2f(fmaf(s[jb][r], c, -mc));
+                s[jb][r] = p;
+                psum += p;
+            }
+        l_run = l_run * alpha + psum;
+#pragma unroll
+        for (int d = 0; d < 2; ++d)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) oacc[d][r] *= alpha;
+
+        // O^T[db] += V^T[db][keys] P^T[keys]
+#pragma unroll
+        for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                bf16x8_t pf;
+#pragma unroll
+                for (int e = 0; e < 8; e += 2) {
+                    const uint32_t pk = pack_bf2(s[jb][8 * ks + e], s[jb][8 * ks + e + 1]);
+                    pf[e] = (short)(pk & 0xffff);
+                    pf[e + 1] = (short)(pk >> 16);
+                }
+                const int jbase = jb * 32 + 16 * ks + 4 * fh;
+#pragma unroll
+                for (int db = 0; db < 2; ++db) {
+                    const char* vp = sv + jbase * V_LD + db * 64 + tr_off;
+                    const bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_bf16x4_t*)(vp));
+                    const bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_bf16x4_t*)(vp + 8 * V_LD));
+                    bf16x8_t vf;
+                    vf[0] = lo[0]; vf[1] = lo[1]; vf[2] = lo[2]; vf[3] = lo[3];
+                    vf[4] = hi[0]; vf[5] = hi[1]; vf[6] = hi[2]; vf[7] = hi[3];
+                    oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, oacc[db], 0, 0, 0);
+                }
+            }
+        if (t + 1 < nt) store_tile(buf ^ 1);
+        __syncthreads();
+    }
+
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float inv = 1.0f / l_tot;
+    if (qrow < Lq) {
+        bf16_t* orow = ob + (size_t)qrow * ldo;
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int qd = 0; qd < 4; ++qd) {
+                const int d = db * 32 + 8 * qd + 4 * fh;
+                float v0 = oacc[db][4 * qd + 0] * inv, v1 = oacc[db][4 * qd + 1] * inv;
+                float v2 = oacc[db][4 * qd + 2] * inv, v3 = oacc[db][4 * qd + 3] * inv;
+                uint2* dst = reinterpret_cast<uint2*>(orow + d);
+                if (accumulate) {
+                    const uint2 old = *dst;
+                    v0 = __uint_as_float(old.x << 16) + acc_scale * v0;
+                    v1 = __uint_as_float(old.x & 0xffff0000u) + acc_scale * v1;
+                    v2 = __uint_as_float(old.y << 16) + acc_scale * v2;
+                    v3 = __uint_as_float(old.y & 0xffff0000u) + acc_scale * v3;
+                }
+                uint2 pk;
+                pk.x = pack_bf2(v0, v1);
+                pk.y = pack_bf2(v2, v3);
+                *dst = pk;
+            }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Temporal attention: one wave per (b, p, head). T <= 16 (rows beyond T are masked).
+//   S^T[t'][t] = K Q^T            : v_mfma_f32_16x16x32_bf16 x2 (d = 64), fragments straight from global
+//   softmax over t' (4 regs x 4 lane groups)
+//   O^T[d][t]  = V^T P^T          : v_mfma_f32_16x16x16_bf16 x4, V^T via LDS + ds_read_b64_tr_b16,
+//                                    P^T is the accumulator itself (lane: col t, rows t' = 4g + r)
+__global__ __launch_bounds__(256) void temporal_attn_d64_kernel(const bf16_t* __restrict__ qkv, int ld,
+                                                                bf16_t* __restrict__ o, int ldo, int B, int T, int HW,
+                                                                int heads, float c, int total) {
+    __shared__ __attribute__((aligned(16))) char smem[4 * 16 * 128];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int item = blockIdx.x * 4 + wave;
+    const bool active = item < total;
+    if (!active) item = total - 1;   // keep the wave in step (EXEC must be full for the transposed LDS read)
+    const int head = item % heads;
+    const int bp = item / heads;
+    const int p = bp % HW;
+    const int b = bp / HW;
+    const int C = heads * 64;
+
+    const int t16 = lane & 15, g = lane >> 4;
+    const int t_c = t16 < T ? t16 : T - 1;
+    const size_t row = ((size_t)b * T + t_c) * HW + p;
+    const bf16_t* rq = qkv + row * ld + head * 64;
+    const bf16_t* rk = rq + C;
+    const bf16_t* rv = rq + 2 * C;
+
+    // fragments: A = K[t'=t16][d = 32s + 8g ..], B = Q[t=t16][same d]
+    bf16x8_t kf[2], qf[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        kf[s] = *reinterpret_cast<const bf16x8_t*>(rk + 32 * s + 8 * g);
+        qf[s] = *reinterpret_cast<const bf16x8_t*>(rq + 32 * s + 8 * g);
+    }
+    // V tile -> LDS (row-major [t'][64], 128-byte rows): lane writes 32 bytes of row (lane>>2), cols 16*(lane&3)..
+    char* sv = smem + wave * (16 * 128);
+    {
+        const int vr = lane >> 2, vc = (lane & 3) * 16;
+        const int vr_c = vr < T ? vr : T - 1;
+        const bf16_t* src = qkv + (((size_t)b * T + vr_c) * HW + p) * ld + head * 64 + 2 * C + vc;
+        uint4 a = *reinterpret_cast<const uint4*>(src);
+        uint4 bq = *reinterpret_cast<const uint4*>(src + 8);
+        if (vr >= T) { a = make_uint4(0, 0, 0, 0); bq = a; }
+        *reinterpret_cast<uint4*>(sv + vr * 128 + vc * 2) = a;
+        *reinterpret_cast<uint4*>(sv + vr * 128 + vc * 2 + 16) = bq;
+    }
+    (void)rv;
+    f32x4_t s4 = {0.f, 0.f, 0.f, 0.f};
+    s4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[0], qf[0], s4, 0, 0, 0);
+    s4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[1], qf[1], s4, 0, 0, 0);
+    // lane: column t = t16, rows t' = 4g + r
+    float mx = -1e30f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        if (4 * g + r >= T) s4[r] = -1e30f;
+        mx = fmaxf(mx, s4[r]);
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    float sum = 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        s4[r] = __builtin_amdgcn_exp2f((s4[r] - mx) * c);
+        sum += s4[r];
+    }
+    sum += __shfl_xor(sum, 16, 64);
+    sum += __shfl_xor(sum, 32, 64);
+    const float inv = 1.0f / sum;
+    bf16x4_t pf;
+    {
+        const uint32_t p01 = pack_bf2(s4[0] * inv, s4[1] * inv), p23 = pack_bf2(s4[2] * inv, s4[3] * inv);
+        pf[0] = (short)(p01 & 0xffff); pf[1] = (short)(p01 >> 16);
+        pf[2] = (short)(p23 & 0xffff); pf[3] = (short)(p23 >> 16);
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): this wave's own LDS writes have landed
+    __builtin_amdgcn_wave_barrier();
+    // O^T[n] (rows d = 16n + 4g + r, col t): A = V^T block n: lane i of group g gets V[4g + 0..3][16n + i]
+    bf16_t* orow = o + row * ldo + head * 64;
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+        const char* vp = sv + (4 * g + (t16 >> 2)) * 128 + (16 * n + (t16 & 3) * 4) * 2;
+        const bf16x4_t vf = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_bf16x4_t*)vp);
+        f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+        acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(vf, pf, acc, 0, 0, 0);
+        if (active && t16 < T) {
+            uint2 pk;
+            pk.x = pack_bf2(acc[0], acc[1]);
+            pk.y = pack_bf2(acc[2], acc[3]);
+            *reinterpret_cast<uint2*>(orow + 16 * n + 4 * g) = pk;
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int dc_flash_attn_d64(const uint16_t* q, const uint16_t* k, const uint16_t* v, uint16_t* o, int ldq, int ldk,
+                                 int ldv, int ldo, int batch, int heads, int Lq, int Lk, int64_t q_bstride,
+                                 int64_t kv_bstride, float scale, int accumulate, float acc_scale, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!q || !k || !v || !o) return DC_ERR_ARG;
+    if (batch <= 0 || heads <= 0 || Lq <= 0 || Lk <= 0) return DC_ERR_SHAPE;
+    if (ldq % 8 || ldk % 8 || ldv % 8 || ldo % 4) return DC_ERR_SHAPE;
+    const int q_tiles = (Lq + FA_BQ - 1) / FA_BQ;
+    const long long nwg = (long long)q_tiles * heads * batch;
+    if (nwg > 0x7fffffffLL) return DC_ERR_SHAPE;
+    const float c = scale * 1.4426950408889634f;
+    hipLaunchKernelGGL(flash_attn_d64_kernel, dim3((unsigned)nwg), dim3(256), 0, stream, q, k, v, o, ldq, ldk, ldv, ldo,
+                       heads, Lq, Lk, q_bstride, kv_bstride, c, accumulate, acc_scale, q_tiles);
+    DC_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int dc_temporal_attn_d64(const uint16_t* qkv, int ld, uint16_t* o, int ldo, int B, int T, int HW, int heads,
+                                    float scale, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!qkv || !o) return DC_ERR_ARG;
+    if (T <= 0 || T > 16 || B <= 0 || HW <= 0 || heads <= 0 || ld % 8 || ldo % 4) return DC_ERR_SHAPE;
+    const long long total = (long long)B * HW * heads;
+    if (total > 0x7fffffffLL) return DC_ERR_SHAPE;
+    const int grid = (int)((total + 3) / 4);
+    const float c = scale * 1.4426950408889634f;
+    hipLaunchKernelGGL(temporal_attn_d64_kernel, dim3(grid), dim3(256), 0, stream, qkv, ld, o, ldo, B, T, HW, heads, c,
+                       (int)total);
+    DC_CHECK_LAUNCH();
+    return 0;
+}

@@ -1,0 +1,18 @@
+#!/bin/bash
+# Builds libdcrafter_hip.so for gfx950 in-tree (next to the sources). hipcc cross-compiles without a GPU.
+set -euo pipefail
+HERE="$(cd "$(dirname "$0")" && pwd)"
+ROOT="$(cd "$HERE/../.." && pwd)"
+OUT="$HERE/libdcrafter_hip.so"
+HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -I$ROOT/include -I$HERE"
+OBJS=()
+pids=()
+for f in gemm_conv norms attention elementwise runtime; do
+  "$HIPCC" $FLAGS -c "$HERE/$f.hip" -o "$HERE/$f.o" &
+  pids+=($!)
+  OBJS+=("$HERE/$f.o")
+done
+for p in "${pids[@]}"; do wait "$p"; done
+"$HIPCC" --offload-arch=gfx950 -shared -fPIC -o "$OUT" "${OBJS[@]}"
+echo "built $OUT"

@@ -1,0 +1,71 @@
+// Shared device helpers for the gfx950 (CDNA4 / MI355X) kernels of the DynamiCrafter denoising path.
+// Wavefront = 64 lanes everywhere in this tree; nothing here is written for any other target.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef uint16_t bf16_t;  // raw bf16 bits; all activations/weights in HBM are bf16 unless a kernel says fp32
+
+typedef __attribute__((ext_vector_type(8))) short bf16x8_t;   // one MFMA A/B fragment (4 VGPRs)
+typedef __attribute__((ext_vector_type(4))) short bf16x4_t;   // 16x16x16 fragment (2 VGPRs)
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;  // 32x32 accumulator
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;    // 16x16 accumulator
+
+#define DC_WAVE 64
+
+__device__ __forceinline__ float bf2f(bf16_t v) {
+    return __uint_as_float(((uint32_t)v) << 16);
+}
+
+// round-to-nearest-even fp32 -> bf16; NaN stays NaN (quiet)
+__device__ __forceinline__ bf16_t f2bf(float f) {
+    uint32_t u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (bf16_t)(u >> 16);
+}
+
+__device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) {
+    return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+}
+
+__device__ __forceinline__ void unpack_bf8(const uint4& v, float* f) {
+    f[0] = __uint_as_float(v.x << 16); f[1] = __uint_as_float(v.x & 0xffff0000u);
+    f[2] = __uint_as_float(v.y << 16); f[3] = __uint_as_float(v.y & 0xffff0000u);
+    f[4] = __uint_as_float(v.z << 16); f[5] = __uint_as_float(v.z & 0xffff0000u);
+    f[6] = __uint_as_float(v.w << 16); f[7] = __uint_as_float(v.w & 0xffff0000u);
+}
+
+__device__ __forceinline__ uint4 pack_bf8(const float* f) {
+    uint4 v;
+    v.x = pack_bf2(f[0], f[1]); v.y = pack_bf2(f[2], f[3]);
+    v.z = pack_bf2(f[4], f[5]); v.w = pack_bf2(f[6], f[7]);
+    return v;
+}
+
+__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+
+// exact (erf) GELU, as torch.nn.functional.gelu default (reference: lvdm/modules/attention.py:422)
+__device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// XCD-aware bijective remap of a linear workgroup id: the 8 XCDs receive workgroups round-robin, so
+// ids b and b+8 share an L2. Give every XCD a contiguous run of logical tiles.
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7;
+    const int xcd = bid & 7, idx = bid >> 3;
+    const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + idx;
+}
+
+#define DC_CHECK_LAUNCH() do { hipError_t e__ = hipGetLastError(); if (e__ != hipSuccess) return (int)e__; } while (0)

@@ -1,0 +1,456 @@
+// Small / memory-bound kernels of the denoising path: embedding MLP GEMVs, sinusoidal embedding, layout packing
+// at the latent / pixel boundaries, concat copies, row softmax, VAE posterior sampling, and the fused DDIM update.
+#include "dc_common.h"
+#include "dcrafter_hip.h"
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------------------
+// out[m][n] = act_out(bias[n] + sum_k act_in(in[m][k]) W[n][k]);  one wave per output column n, M <= 8.
+__global__ __launch_bounds__(256) void gemv_small_kernel(const float* __restrict__ in, int ld_in,
+                                                         const bf16_t* __restrict__ W, const float* __restrict__ bias,
+                                                         float* __restrict__ out, int ld_out, int M, int N, int K,
+                                                         int act_in, int act_out, int accumulate) {
+    const int lane = threadIdx.x & 63;
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= N) return;
+    float acc[8];
+#pragma unroll
+    for (int m = 0; m < 8; ++m) acc[m] = 0.f;
+    const bf16_t* wrow = W + (size_t)n * K;
+    for (int k0 = lane * 8; k0 < K; k0 += 64 * 8) {
+        const uint4 raw = *reinterpret_cast<const uint4*>(wrow + k0);
+        float w[8];
+        unpack_bf8(raw, w);
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+            if (m < M) {
+                const float* x = in + (size_t)m * ld_in + k0;
+                float s = 0.f;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    float xv = x[e];
+                    if (act_in == 1) xv = silu_f(xv);
+                    s += xv * w[e];
+                }
+                acc[m] += s;
+            }
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+        if (m < M) {
+            float s = wave_sum(acc[m]);
+            if (lane == 0) {
+                if (bias) s += bias[n];
+                if (act_out == 1) s = silu_f(s);
+                float* dst = out + (size_t)m * ld_out + n;
+                *dst = accumulate ? (*dst + s) : s;
+            }
+        }
+    }
+}
+
+__global__ void timestep_embedding_kernel(const int64_t* __restrict__ t_table, const int32_t* __restrict__ t_index,
+                                          int t_stride, float* __restrict__ out, int B, int dim, float log_max_period) {
+    const int half = dim / 2;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= B * half) return;
+    const int b = idx / half, i = idx - b * half;
+    const int64_t off = t_index ? (int64_t)t_index[0] * t_stride : 0;
+    const float t = (float)t_table[off + b];
+    // freqs = exp(-ln(max_period) * i / half) in fp32, args = t * freqs (utils_diffusion.py:19-23)
+    const float freq = expf(-log_max_period * (float)i / (float)half);
+    const float arg = t * freq;
+    out[(size_t)b * dim + i] = cosf(arg);
+    out[(size_t)b * dim + half + i] = sinf(arg);
+    if ((dim & 1) && i == 0) out[(size_t)b * dim + dim - 1] = 0.f;
+}
+
+// x [B][Cx][T*HW], cc [B][Cc][T*HW] fp32 -> rows [nrep][B][T*HW][c_pad] bf16
+__global__ void pack_latent_kernel(const float* __restrict__ x, const float* __restrict__ cc, bf16_t* __restrict__ out,
+                                   int B, int Cx, int Cc, int THW, int c_pad, int nrep) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // one thread per (b, pos)
+    const int64_t total = (int64_t)B * THW;
+    if (idx >= total) return;
+    const int b = (int)(idx / THW);
+    const int pos = (int)(idx - (int64_t)b * THW);
+    for (int c0 = 0; c0 < c_pad; c0 += 8) {
+        float f[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int c = c0 + e;
+            float v = 0.f;
+            if (c < Cx) v = x[((size_t)b * Cx + c) * THW + pos];
+            else if (c < Cx + Cc) v = cc[((size_t)b * Cc + (c - Cx)) * THW + pos];
+            f[e] = v;
+        }
+        const uint4 pk = pack_bf8(f);
+        for (int r = 0; r < nrep; ++r)
+            *reinterpret_cast<uint4*>(out + ((size_t)r * total + idx) * c_pad + c0) = pk;
+    }
+}
+
+__global__ void nchw_to_rows_kernel(const float* __restrict__ x, bf16_t* __restrict__ out, int N, int C, int HW,
+                                    int c_pad, float scale) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t total = (int64_t)N * HW;
+    if (idx >= total) return;
+    const int n = (int)(idx / HW);
+    const int pos = (int)(idx - (int64_t)n * HW);
+    for (int c0 = 0; c0 < c_pad; c0 += 8) {
+        float f[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int c = c0 + e;
+            f[e] = (c < C) ? x[((size_t)n * C + c) * HW + pos] * scale : 0.f;
+        }
+        *reinterpret_cast<uint4*>(out + (size_t)idx * c_pad + c0) = pack_bf8(f);
+    }
+}
+
+__global__ void rows_to_nchw_kernel(const void* __restrict__ rows, int ld, int rows_f32, float* __restrict__ y, int N,
+                                    int C, int HW, float scale) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t total = (int64_t)N * HW;
+    if (idx >= total) return;
+    const int n = (int)(idx / HW);
+    const int pos = (int)(idx - (int64_t)n * HW);
+    for (int c = 0; c < C; ++c) {
+        float v;
+        if (rows_f32) v = reinterpret_cast<const float*>(rows)[(size_t)idx * ld + c];
+        else v = bf2f(reinterpret_cast<const bf16_t*>(rows)[(size_t)idx * ld + c]);
+        y[((size_t)n * C + c) * HW + pos] = v * scale;
+    }
+}
+
+__global__ void copy2d_kernel(const bf16_t* __restrict__ src, int lds_, bf16_t* __restrict__ dst, int ldd, int rows,
+                              int vecs) {
+    const int64_t total = (int64_t)rows * vecs;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (int64_t)gridDim.x * blockDim.x) {
+        const int r = (int)(idx / vecs);
+        const int v = (int)(idx - (int64_t)r * vecs);
+        *reinterpret_cast<uint4*>(dst + (size_t)r * ldd + v * 8) =
+            *reinterpret_cast<const uint4*>(src + (size_t)r * lds_ + v * 8);
+    }
+}
+
+__global__ void add_rows_kernel(const bf16_t* __restrict__ a, int lda, const bf16_t* __restrict__ b, int ldb,
+                                bf16_t* __restrict__ y, int ldy, int rows, int vecs) {
+    const int64_t total = (int64_t)rows * vecs;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (int64_t)gridDim.x * blockDim.x) {
+        const int r = (int)(idx / vecs);
+        const int v = (int)(idx - (int64_t)r * vecs);
+        float fa[8], fb[8];
+        unpack_bf8(*reinterpret_cast<const uint4*>(a + (size_t)r * lda + v * 8), fa);
+        unpack_bf8(*reinterpret_cast<const uint4*>(b + (size_t)r * ldb + v * 8), fb);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) fa[e] += fb[e];
+        *reinterpret_cast<uint4*>(y + (size_t)r * ldy + v * 8) = pack_bf8(fa);
+    }
+}
+
+// ctx [B][n_text + T*L][D] fp32 -> out [B*T][n_text + L][D] bf16
+__global__ void build_context_kernel(const float* __restrict__ ctx, bf16_t* __restrict__ out, int B, int T, int n_text,
+                                     int L, int D) {
+    const int vecs = D / 8;
+    const int per_frame = (n_text + L) * vecs;
+    const int64_t total = (int64_t)B * T * per_frame;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (int64_t)gridDim.x * blockDim.x) {
+        const int f = (int)(idx / per_frame);
+        const int rem = (int)(idx - (int64_t)f * per_frame);
+        const int tok = rem / vecs, v = rem - tok * vecs;
+        const int b = f / T, t = f - b * T;
+        const int src_tok = tok < n_text ? tok : n_text + t * L + (tok - n_text);
+        const float* s = ctx + ((size_t)b * (n_text + T * L) + src_tok) * D + v * 8;
+        float fv[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) fv[e] = s[e];
+        *reinterpret_cast<uint4*>(out + ((size_t)f * (n_text + L) + tok) * D + v * 8) = pack_bf8(fv);
+    }
+}
+
+// one workgroup per row; cols arbitrary
+__global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restrict__ x, int ldx, bf16_t* __restrict__ y,
+                                                           int ldy, int cols) {
+    __shared__ float red[4];
+    const int row = blockIdx.x;
+    const float* xr = x + (size_t)row * ldx;
+    bf16_t* yr = y + (size_t)row * ldy;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float mx = -3.0e38f;
+    for (int c = threadIdx.x; c < cols; c += 256) mx = fmaxf(mx, xr[c]);
+    mx = wave_max(mx);
+    if (lane == 0) red[wave] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    __syncthreads();
+    float s = 0.f;
+    for (int c = threadIdx.x; c < cols; c += 256) s += __expf(xr[c] - mx);
+    s = wave_sum(s);
+    if (lane == 0) red[wave] = s;
+    __syncthreads();
+    s = (red[0] + red[1]) + (red[2] + red[3]);
+    const float inv = 1.0f / s;
+    for (int c = threadIdx.x; c < cols; c += 256) yr[c] = f2bf(__expf(xr[c] - mx) * inv);
+}
+
+__global__ void vae_sample_kernel(const bf16_t* __restrict__ mom, int ld, const float* __restrict__ noise,
+                                  float* __restrict__ z, int N, int zc, int HW, float scale) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t total = (int64_t)N * HW;
+    if (idx >= total) return;
+    const int n = (int)(idx / HW);
+    const int pos = (int)(idx - (int64_t)n * HW);
+    for (int c = 0; c < zc; ++c) {
+        const float mean = bf2f(mom[(size_t)idx * ld + c]);
+        float lv = bf2f(mom[(size_t)idx * ld + zc + c]);
+        lv = fminf(fmaxf(lv, -30.f), 20.f);
+        float v = mean;
+        if (noise) v += expf(0.5f * lv) * noise[((size_t)n * zc + c) * HW + pos];
+        z[((size_t)n * zc + c) * HW + pos] = v * scale;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// DDIM update. Pass 1 (many workgroups): model_output = e_u + s (e_c - e_u) [+ 3-branch], per-block partial
+// sums of {cfg, cfg^2, e_c, e_c^2} per sample. Pass 2: every workgroup re-reduces the (few) partials in a fixed
+// order, then applies guidance rescale, v->eps/x0, dynamic rescale and the DDIM step elementwise.
+constexpr int DDIM_BLOCKS = 256;   // partial blocks per sample
+
+__device__ __forceinline__ float ddim_cfg(const DcDdimParams& p, const float* ec, const float* eu, const float* ei,
+                                          size_t off) {
+    const float c = ec[off];
+    if (!eu) return c;
+    const float u = eu[off];
+    if (ei) {   // e_u + cfg_img (e_ui - e_u) + s (e_c - e_ui)   (ddim_multiplecond.py:234)
+        const float ui = ei[off];
+        return u + p.cfg_img * (ui - u) + p.cfg_scale * (c - ui);
+    }
+    return u + p.cfg_scale * (c - u);
+}
+
+__global__ __launch_bounds__(256) void ddim_partial_kernel(const DcDdimParams p, const float* __restrict__ ec,
+                                                           const float* __restrict__ eu, const float* __restrict__ ei,
+                                                           int ld_e, int C, int THW, float* __restrict__ ws) {
+    __shared__ float red[4][4];
+    const int b = blockIdx.y;
+    const int64_t n = (int64_t)C * THW;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)DDIM_BLOCKS * 256) {
+        const int pos = (int)(i / C), c = (int)(i - (int64_t)pos * C);
+        const size_t off = ((size_t)b * THW + pos) * ld_e + c;
+        const float cfg = ddim_cfg(p, ec, eu, ei, off);
+        const float e = ec[off];
+        s0 += cfg; s1 += cfg * cfg; s2 += e; s3 += e * e;
+    }
+    s0 = wave_sum(s0); s1 = wave_sum(s1); s2 = wave_sum(s2); s3 = wave_sum(s3);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) { red[wave][0] = s0; red[wave][1] = s1; red[wave][2] = s2; red[wave][3] = s3; }
+    __syncthreads();
+    if (threadIdx.x < 4) {
+        const float t = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+        ws[((size_t)b * DDIM_BLOCKS + blockIdx.x) * 4 + threadIdx.x] = t;
+    }
+}
+
+__global__ __launch_bounds__(256) void ddim_apply_kernel(const DcDdimParams p, const float* __restrict__ ec,
+                                                         const float* __restrict__ eu, const float* __restrict__ ei,
+                                                         int ld_e, const float* __restrict__ x,
+                                                         const float* __restrict__ noise, float* __restrict__ x_prev,
+                                                         float* __restrict__ pred_x0, int C, int THW,
+                                                         const float* __restrict__ ws) {
+    __shared__ double tot[4];
+    const int b = blockIdx.y;
+    const int64_t n = (int64_t)C * THW;
+    float factor = 1.0f;   // guidance rescale: cfg * (phi*std_text/std_cfg + 1 - phi)
+    if (p.guidance_rescale > 0.f && eu) {
+        if (threadIdx.x < 4) {
+            double t = 0.0;
+            for (int k = 0; k < DDIM_BLOCKS; ++k) t += (double)ws[((size_t)b * DDIM_BLOCKS + k) * 4 + threadIdx.x];
+            tot[threadIdx.x] = t;
+        }
+        __syncthreads();
+        const double cnt = (double)n;
+        // unbiased std (torch.std default), utils_diffusion.py:152-153
+        const double mean_cfg = tot[0] / cnt, mean_txt = tot[2] / cnt;
+        const double var_cfg = fmax(tot[1] - cnt * mean_cfg * mean_cfg, 0.0) / (cnt - 1.0);
+        const double var_txt = fmax(tot[3] - cnt * mean_txt * mean_txt, 0.0) / (cnt - 1.0);
+        const float ratio = (float)sqrt(var_txt) / (float)sqrt(var_cfg);
+        factor = p.guidance_rescale * ratio + (1.f - p.guidance_rescale);
+    }
+    const int idx = p.step_index ? p.step_index[0] : p.index;
+    const float a_t = p.a_t[idx], a_prev = p.a_prev[idx], sigma = p.sigma_t[idx], s1m = p.sqrt_one_minus_at[idx];
+    const float sq_acp = p.v_param ? p.sqrt_acp_t[idx] : 0.f;
+    const float sq_1macp = p.v_param ? p.sqrt_1macp_t[idx] : 0.f;
+    const float resc = p.scale_ratio ? p.scale_ratio[idx] : 1.0f;
+    const float sqrt_at = sqrtf(a_t);
+    const float sqrt_aprev = sqrtf(a_prev);
+    // (1 - a_prev - sigma^2).sqrt() in fp32, same association as ddim.py:271. With zero-terminal-SNR +
+    // uniform_trailing + eta=1 the radicand is +5.96e-8 at the first step; clamp at 0 so a one-ulp
+    // difference can never produce NaN (the reference's get_fixed_ddim_sampler exists for that hazard).
+    const float dir_coef = sqrtf(fmaxf(1.f - a_prev - sigma * sigma, 0.f));
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const int c = (int)(i / THW), pos = (int)(i - (int64_t)c * THW);     // NCTHW order for x / outputs
+        const size_t eoff = ((size_t)b * THW + pos) * ld_e + c;
+        const size_t xoff = (size_t)b * n + i;
+        const float mo = ddim_cfg(p, ec, eu, ei, eoff) * factor;
+        const float xv = x[xoff];
+        float e_t, px0;
+        if (p.v_param) {
+            e_t = sq_acp * mo + sq_1macp * xv;      // predict_eps_from_z_and_v  ddpm3d.py:247-251
+            px0 = sq_acp * xv - sq_1macp * mo;      // predict_start_from_z_and_v ddpm3d.py:239-245
+        } else {
+            e_t = mo;
+            px0 = (xv - s1m * e_t) / sqrt_at;       // ddim.py:258
+        }
+        px0 *= resc;                                 // ddim.py:262-266
+        const float nz = noise ? sigma * noise[xoff] * p.temperature : 0.f;
+        x_prev[xoff] = sqrt_aprev * px0 + dir_coef * e_t + nz;   // ddim.py:271-277
+        pred_x0[xoff] = px0;
+    }
+}
+
+__global__ void advance_counter_kernel(int32_t* c) { if (threadIdx.x == 0 && blockIdx.x == 0) c[0] += 1; }
+
+inline int grid_for(int64_t total, int block, int cap) {
+    int64_t g = (total + block - 1) / block;
+    if (g > cap) g = cap;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+}  // namespace
+
+extern "C" int dc_gemv_small(const float* in, int ld_in, const uint16_t* W, const float* bias, float* out, int ld_out,
+                             int M, int N, int K, int act_in, int act_out, int accumulate, void* stream_) {
+    if (!in || !W || !out) return DC_ERR_ARG;
+    if (M < 1 || M > 8 || N < 1 || K % 8 != 0) return DC_ERR_SHAPE;
+    hipLaunchKernelGGL(gemv_small_kernel, dim3((N + 3) / 4), dim3(256), 0, (hipStream_t)stream_, in, ld_in, W, bias, out,
+                       ld_out, M, N, K, act_in, act_out, accumulate);
+    DC_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int dc_timestep_embedding(const int64_t* t_table, const int32_t* t_index, int t_stride, float* out, int B,
+                                     int dim, float max_period, void* stream_) {
+    if (!t_table || !out) return DC_ERR_ARG;
+    if (B < 1 || dim < 2) return DC_ERR_SHAPE;
+    const int total = B * (dim / 2);
+    hipLaunchKernelGGL(timestep_embedding_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream_, t_table,
+                       t_index, t_stride, out, B, dim, logf(max_period));
+    DC_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int dc_pack_latent(const float* x, const float* cc, uint16_t* out, int B, int Cx, int Cc, int T, int HW,
+                              int c_pad, int nrep, void* stream_) {
+    if (!x || !out || (Cc > 0 && !cc)) return DC_ERR_ARG;
+    if (c_pad % 8 != 0 || c_pad < Cx + Cc || nrep < 1) return DC_ERR_SHAPE;
+    const int64_t total = (int64_t)B * T * HW;
+    hipLaunchKernelGGL(pack_latent_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream_, x,
+                       cc, out, B, Cx, Cc, T * HW, c_pad, nrep);
+    DC_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int dc_nchw_to_rows(const float* x, uint16_t* out, int N, int C, int HW, int c_pad, float scale,
+                               void* stream_) {
+    if (!x || !out) return DC_ERR_ARG;
+    if (c_pad % 8 != 0 || c_pad < C) return DC_ERR_SHAPE;
+    const int64_t total = (int64_t)N * HW;
+    hipLaunchKernelGGL(nchw_to_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream_, x,
+                       out, N, C, HW, c_pad, scale);
+    DC_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int dc_rows_to_nchw(const void* rows, int ld, int rows_f32, float* y, int N, int C, int HW, float scale,
+                               void* stream_) {
+    if (!rows || !y) return DC_ERR_ARG;
+    const int64_t total = (int64_t)N * HW;
+    hipLaunchKernelGGL(rows_to_nchw_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream_,
+                       rows, ld, rows_f32, y, N, C, HW, scale);
+    DC_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int dc_copy2d(const uint16_t* src, int lds_, uint16_t* dst, int ldd, int rows, int cols, void* stream_) {
+    if (!src || !dst) return DC_ERR_ARG;
+    if (cols % 8 || lds_ % 8 || ldd % 8 || rows < 1) return DC_ERR_SHAPE;
+    const int64_t total = (int64_t)rows * (cols / 8);
+    hipLaunchKernelGGL(copy2d_kernel, dim3(grid_for(total, 256, 8192)), dim3(256), 0, (hipStream_t)stream_, src, lds_, dst,
+                       ldd, rows, cols / 8);
+    DC_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int dc_add_rows(const uint16_t* a, int lda, const uint16_t* b, int ldb, uint16_t* y, int ldy, int rows,
+                           int cols, void* stream_) {
+    if (!a || !b || !y) return DC_ERR_ARG;
+    if (cols % 8 || lda % 8 || ldb % 8 || ldy % 8 || rows < 1) return DC_ERR_SHAPE;
+    const int64_t total = (int64_t)rows * (cols / 8);
+    hipLaunchKernelGGL(add_rows_kernel, dim3(grid_for(total, 256, 8192)), dim3(256), 0, (hipStream_t)stream_, a, lda, b,
+                       ldb, y, ldy, rows, cols / 8);
+    DC_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int dc_build_context(const float* ctx, uint16_t* out, int B, int T, int n_text, int L, int D, void* stream_) {
+    if (!ctx || !out) return DC_ERR_ARG;
+    if (D % 8 || B < 1 || T < 1 || n_text < 0 || L < 0) return DC_ERR_SHAPE;
+    const int64_t total = (int64_t)B * T * (n_text + L) * (D / 8);
+    hipLaunchKernelGGL(build_context_kernel, dim3(grid_for(total, 256, 8192)), dim3(256), 0, (hipStream_t)stream_, ctx, out,
+                       B, T, n_text, L, D);
+    DC_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int dc_softmax_rows(const float* x, int ldx, uint16_t* y, int ldy, int rows, int cols, void* stream_) {
+    if (!x || !y) return DC_ERR_ARG;
+    if (rows < 1 || cols < 1) return DC_ERR_SHAPE;
+    hipLaunchKernelGGL(softmax_rows_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream_, x, ldx, y, ldy, cols);
+    DC_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int dc_vae_sample(const uint16_t* moments, int ld, const float* noise, float* z, int N, int zc, int HW,
+                             float scale, void* stream_) {
+    if (!moments || !z) return DC_ERR_ARG;
+    const int64_t total = (int64_t)N * HW;
+    hipLaunchKernelGGL(vae_sample_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream_,
+                       moments, ld, noise, z, N, zc, HW, scale);
+    DC_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int dc_ddim_step(const DcDdimParams* pp, const float* e_cond, const float* e_uncond, const float* e_img,
+                            int ld_e, const float* x, const float* noise, float* x_prev, float* pred_x0, int B, int C,
+                            int THW, float* workspace, void* stream_) {
+    if (!pp || !e_cond || !x || !x_prev || !pred_x0 || !workspace) return DC_ERR_ARG;
+    const DcDdimParams& p = *pp;
+    if (!p.a_t || !p.a_prev || !p.sigma_t || !p.sqrt_one_minus_at) return DC_ERR_ARG;
+    if (p.v_param && (!p.sqrt_acp_t || !p.sqrt_1macp_t)) return DC_ERR_ARG;
+    if (B < 1 || C < 1 || THW < 1) return DC_ERR_SHAPE;
+    hipStream_t stream = (hipStream_t)stream_;
+    if (p.guidance_rescale > 0.f && e_uncond) {
+        hipLaunchKernelGGL(ddim_partial_kernel, dim3(DDIM_BLOCKS, B), dim3(256), 0, stream, p, e_cond, e_uncond, e_img,
+                           ld_e, C, THW, workspace);
+        DC_CHECK_LAUNCH();
+    }
+    const int64_t n = (int64_t)C * THW;
+    hipLaunchKernelGGL(ddim_apply_kernel, dim3(grid_for(n, 256, 1024), B), dim3(256), 0, stream, p, e_cond, e_uncond,
+                       e_img, ld_e, x, noise, x_prev, pred_x0, C, THW, workspace);
+    DC_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int dc_advance_counter(int32_t* counter, void* stream_) {
+    if (!counter) return DC_ERR_ARG;
+    hipLaunchKernelGGL(advance_counter_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream_, counter);
+    DC_CHECK_LAUNCH();
+    return 0;
+}

@@ -1,0 +1,234 @@
+// GroupNorm(+SiLU) and LayerNorm over channels-last bf16 rows; fp32 statistics. HBM-bound kernels:
+// 16-byte loads/stores per lane, each row read twice (stats pass + apply pass) and written once.
+//
+// GroupNorm is three launches: partial sums per (instance, row-chunk, group) -> finalize (mean, rstd) per
+// (instance, group) -> normalise*affine(+SiLU). All reductions have a fixed order: results are bitwise
+// reproducible run to run.
+//   reference: GroupNormSpecific lvdm/basics.py:76-87 (eps 1e-5, fp32), nn.GroupNorm(32, C) in
+//   TemporalConvBlock openaimodel3d.py:256-265 (5-D: statistics span T*H*W), transformer norms
+//   attention.py:265,331 (eps 1e-6), AE Normalize ae_modules.py:15-16 (eps 1e-6) + swish :10-12.
+#include "dc_common.h"
+#include "dcrafter_hip.h"
+
+namespace {
+
+struct GnGeom { int chunks; int rows_per_chunk; };
+
+__host__ __device__ inline GnGeom gn_geom(int n_inst, int rows_per_inst) {
+    int chunks = (2048 + n_inst - 1) / n_inst;
+    int rpc = (rows_per_inst + chunks - 1) / chunks;
+    if (rpc < 32) rpc = 32;
+    GnGeom g;
+    g.rows_per_chunk = rpc;
+    g.chunks = (rows_per_inst + rpc - 1) / rpc;
+    return g;
+}
+
+// grid (chunks, n_inst), block = vecs * rpp threads (vecs = C/8)
+__global__ void gn_partial_kernel(const bf16_t* __restrict__ x, int ldx, int C, int groups, int rows_per_inst,
+                                  int rows_per_chunk, int chunks, int vecs, int rpp, float2* __restrict__ partial) {
+    extern __shared__ float sm[];   // [2][rpp][C]
+    const int inst = blockIdx.y, chunk = blockIdx.x;
+    const int v = threadIdx.x % vecs;
+    const int ro = threadIdx.x / vecs;
+    const int r_begin = chunk * rows_per_chunk;
+    int r_end = r_begin + rows_per_chunk;
+    if (r_end > rows_per_inst) r_end = rows_per_inst;
+    float s[8], ss[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { s[e] = 0.f; ss[e] = 0.f; }
+    const bf16_t* base = x + (size_t)inst * rows_per_inst * ldx + v * 8;
+    for (int r = r_begin + ro; r < r_end; r += rpp) {
+        const uint4 raw = *reinterpret_cast<const uint4*>(base + (size_t)r * ldx);
+        float f[8];
+        unpack_bf8(raw, f);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { s[e] += f[e]; ss[e] += f[e] * f[e]; }
+    }
+    float* sm_s = sm;
+    float* sm_q = sm + rpp * C;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        sm_s[ro * C + v * 8 + e] = s[e];
+        sm_q[ro * C + v * 8 + e] = ss[e];
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < groups) {
+        const int cpg = C / groups;
+        const int g = threadIdx.x;
+        float a = 0.f, b = 0.f;
+        for (int rr = 0; rr < rpp; ++rr)
+            for (int c = 0; c < cpg; ++c) {
+                a += sm_s[rr * C + g * cpg + c];
+                b += sm_q[rr * C + g * cpg + c];
+            }
+        partial[((size_t)inst * chunks + chunk) * groups + g] = make_float2(a, b);
+    }
+}
+
+// grid n_inst, block 256: reduce chunks partials per group in a fixed order -> (mean, rstd)
+__global__ void gn_finalize_kernel(const float2* __restrict__ partial, int chunks, int groups, float count, float eps,
+                                   float2* __restrict__ stats) {
+    __shared__ float2 red[256];
+    const int inst = blockIdx.x;
+    const int g = threadIdx.x % groups;
+    const int part = threadIdx.x / groups;
+    const int nparts = 256 / groups;
+    float a = 0.f, b = 0.f;
+    if (part < nparts) {
+        for (int c = part; c < chunks; c += nparts) {
+            const float2 p = partial[((size_t)inst * chunks + c) * groups + g];
+            a += p.x; b += p.y;
+        }
+    }
+    red[threadIdx.x] = make_float2(a, b);
+    __syncthreads();
+    if ((int)threadIdx.x < groups) {
+        float sa = 0.f, sb = 0.f;
+        for (int q = 0; q < nparts; ++q) { sa += red[q * groups + g].x; sb += red[q * groups + g].y; }
+        const float mean = sa / count;
+        float var = sb / count - mean * mean;
+        if (var < 0.f) var = 0.f;
+        stats[(size_t)inst * groups + g] = make_float2(mean, rsqrtf(var + eps));
+    }
+}
+
+__global__ void gn_apply_kernel(const bf16_t* __restrict__ x, int ldx, bf16_t* __restrict__ y, int ldy,
+                                const float* __restrict__ gamma, const float* __restrict__ beta, int C, int groups,
+                                int rows_per_inst, int rows_per_chunk, int vecs, int rpp, int silu,
+                                const float2* __restrict__ stats) {
+    const int inst = blockIdx.y, chunk = blockIdx.x;
+    const int v = threadIdx.x % vecs;
+    const int ro = threadIdx.x / vecs;
+    const int r_begin = chunk * rows_per_chunk;
+    int r_end = r_begin + rows_per_chunk;
+    if (r_end > rows_per_inst) r_end = rows_per_inst;
+    const int cpg = C / groups;
+    float sc[8], sh[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int c = v * 8 + e;
+        const float2 st = stats[(size_t)inst * groups + c / cpg];
+        const float g = gamma[c] * st.y;
+        sc[e] = g;
+        sh[e] = beta[c] - st.x * g;
+    }
+    const bf16_t* xb = x + (size_t)inst * rows_per_inst * ldx + v * 8;
+    bf16_t* yb = y + (size_t)inst * rows_per_inst * ldy + v * 8;
+    for (int r = r_begin + ro; r < r_end; r += rpp) {
+        const uint4 raw = *reinterpret_cast<const uint4*>(xb + (size_t)r * ldx);
+        float f[8];
+        unpack_bf8(raw, f);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float t = f[e] * sc[e] + sh[e];
+            if (silu) t = silu_f(t);
+            f[e] = t;
+        }
+        *reinterpret_cast<uint4*>(yb + (size_t)r * ldy) = pack_bf8(f);
+    }
+}
+
+// one wave per row, MAXV 16-byte vectors per lane
+template <int MAXV>
+__global__ __launch_bounds__(256) void layernorm_kernel(const bf16_t* __restrict__ x, int ldx, bf16_t* __restrict__ y,
+                                                        int ldy, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, int rows, int C, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int vecs = C >> 3;
+    const float invC = 1.0f / (float)C;
+    for (int row = blockIdx.x * 4 + wave; row < rows; row += gridDim.x * 4) {
+        float f[MAXV][8];
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < MAXV; ++j) {
+            const int v = lane + 64 * j;
+            if (v < vecs) {
+                const uint4 raw = *reinterpret_cast<const uint4*>(x + (size_t)row * ldx + v * 8);
+                unpack_bf8(raw, f[j]);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) s += f[j][e];
+            }
+        }
+        const float mean = wave_sum(s) * invC;
+        float q = 0.f;
+#pragma unroll
+        for (int j = 0; j < MAXV; ++j) {
+            const int v = lane + 64 * j;
+            if (v < vecs) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { const float d = f[j][e] - mean; q += d * d; }
+            }
+        }
+        const float rstd = rsqrtf(wave_sum(q) * invC + eps);
+#pragma unroll
+        for (int j = 0; j < MAXV; ++j) {
+            const int v = lane + 64 * j;
+            if (v < vecs) {
+                float o[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int c = v * 8 + e;
+                    o[e] = (f[j][e] - mean) * rstd * gamma[c] + beta[c];
+                }
+                *reinterpret_cast<uint4*>(y + (size_t)row * ldy + v * 8) = pack_bf8(o);
+            }
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int64_t dc_groupnorm_workspace_bytes(int n_inst, int groups, int rows_per_inst) {
+    const GnGeom g = gn_geom(n_inst, rows_per_inst);
+    return (int64_t)sizeof(float2) * ((int64_t)n_inst * g.chunks * groups + (int64_t)n_inst * groups) + 256;
+}
+
+extern "C" int dc_groupnorm(const uint16_t* x, int ldx, uint16_t* y, int ldy, const float* gamma, const float* beta,
+                            int C, int groups, int n_inst, int rows_per_inst, float eps, int silu,
+                            float* workspace, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!x || !y || !gamma || !beta || !workspace) return DC_ERR_ARG;
+    if (C % 8 != 0 || groups <= 0 || groups > 64 || C % groups != 0 || ldx % 8 != 0 || ldy % 8 != 0) return DC_ERR_SHAPE;
+    if (n_inst <= 0 || rows_per_inst <= 0) return DC_ERR_SHAPE;
+    const int vecs = C / 8;
+    if (vecs > 1024) return DC_ERR_SHAPE;
+    int rpp = 256 / vecs;
+    if (rpp < 1) rpp = 1;
+    const int threads = vecs * rpp;
+    const GnGeom g = gn_geom(n_inst, rows_per_inst);
+    float2* partial = reinterpret_cast<float2*>(workspace);
+    float2* stats = partial + (size_t)n_inst * g.chunks * groups;
+    const size_t lds = (size_t)2 * rpp * C * sizeof(float);
+    if (lds > 64 * 1024) return DC_ERR_SHAPE;
+    hipLaunchKernelGGL(gn_partial_kernel, dim3(g.chunks, n_inst), dim3(threads), lds, stream, x, ldx, C, groups,
+                       rows_per_inst, g.rows_per_chunk, g.chunks, vecs, rpp, partial);
+    DC_CHECK_LAUNCH();
+    const float count = (float)rows_per_inst * (float)(C / groups);
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(n_inst), dim3(256), 0, stream, partial, g.chunks, groups, count, eps,
+                       stats);
+    DC_CHECK_LAUNCH();
+    hipLaunchKernelGGL(gn_apply_kernel, dim3(g.chunks, n_inst), dim3(threads), 0, stream, x, ldx, y, ldy, gamma, beta,
+                       C, groups, rows_per_inst, g.rows_per_chunk, vecs, rpp, silu, stats);
+    DC_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int dc_layernorm(const uint16_t* x, int ldx, uint16_t* y, int ldy, const float* gamma, const float* beta,
+                            int rows, int C, float eps, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!x || !y || !gamma || !beta) return DC_ERR_ARG;
+    if (C % 8 != 0 || C > 2048 || ldx % 8 != 0 || ldy % 8 != 0 || rows <= 0) return DC_ERR_SHAPE;
+    int grid = (rows + 3) / 4;
+    if (grid > 8192) grid = 8192;
+    const int vecs = C / 8;
+    if (vecs <= 64)
+        hipLaunchKernelGGL(layernorm_kernel<1>, dim3(grid), dim3(256), 0, stream, x, ldx, y, ldy, gamma, beta, rows, C, eps);
+    else if (vecs <= 128)
+        hipLaunchKernelGGL(layernorm_kernel<2>, dim3(grid), dim3(256), 0, stream, x, ldx, y, ldy, gamma, beta, rows, C, eps);
+    else
+        hipLaunchKernelGGL(layernorm_kernel<4>, dim3(grid), dim3(256), 0, stream, x, ldx, y, ldy, gamma, beta, rows, C, eps);
+    DC_CHECK_LAUNCH();
+    return 0;
+}

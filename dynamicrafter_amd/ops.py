@@ -1,0 +1,308 @@
+"""Tensor-level wrappers over the C ABI (include/dcrafter_hip.h).
+
+Every function takes torch CUDA tensors purely as (pointer, stride) carriers and enqueues HIP kernels on the
+current torch stream. Activations are channels-last bf16 rows: 2-D tensors [rows, C] with stride (ld, 1).
+Nothing here computes with torch.
+"""
+import ctypes as C
+import math
+
+import torch
+
+from . import _hip
+from ._hip import DcDdimParams, DcGemmParams, check
+
+_BF16 = torch.bfloat16
+
+
+def stream_ptr():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return C.c_void_p(0 if t is None else t.data_ptr())
+
+
+def _rows(t, name="tensor", dtype=_BF16):
+    if t.dtype != dtype or t.dim() != 2 or t.stride(1) != 1 or not t.is_cuda:
+        raise ValueError(f"{name}: expected CUDA {dtype} rows [R, C] with unit column stride, got "
+                         f"{t.dtype} {tuple(t.shape)} strides {t.stride()} on {t.device}")
+    return t
+
+
+class PackedWeight:
+    """Device copy of a Linear / conv weight in the layout dc_gemm_conv consumes: bf16 [n_pad][K], K ordered
+    (tap, ci), rows zero-padded to a multiple of 128. Derived from the nn.Parameter, never serialised."""
+
+    __slots__ = ("w", "bias", "N", "K", "n_pad", "Cin", "taps")
+
+    def __init__(self, w, bias, N, K, Cin, taps):
+        self.w, self.bias, self.N, self.K, self.Cin, self.taps = w, bias, N, K, Cin, taps
+        self.n_pad = w.shape[0]
+
+    @staticmethod
+    def _finish(w2d, bias, device, Cin, taps, pad_n_to=None):
+        N, K = w2d.shape
+        n_pad = (N + 127) // 128 * 128
+        if pad_n_to is not None:
+            n_pad = max(n_pad, pad_n_to)
+        wp = torch.zeros((n_pad, K), dtype=_BF16, device=device)
+        wp[:N] = w2d.to(device=device, dtype=_BF16)
+        b = None if bias is None else bias.detach().to(device=device, dtype=torch.float32).contiguous()
+        return PackedWeight(wp, b, N, K, Cin, taps)
+
+    @staticmethod
+    def linear(weight, bias, device, n_align=1):
+        """nn.Linear / Conv1d(k=1) / Conv2d(k=1) weight [N, K, ...]. n_align pads N (zero rows + zero bias)."""
+        w = weight.detach().reshape(weight.shape[0], -1)
+        N, K = w.shape
+        if K % 64 != 0:
+            kp = (K + 63) // 64 * 64
+            w = torch.nn.functional.pad(w, (0, kp - K))
+        if N % n_align != 0:
+            npad = (N + n_align - 1) // n_align * n_align
+            w = torch.nn.functional.pad(w, (0, 0, 0, npad - N))
+            if bias is not None:
+                bias = torch.nn.functional.pad(bias.detach(), (0, npad - N))
+        return PackedWeight._finish(w, bias, device, w.shape[1], 1)
+
+    @staticmethod
+    def conv3x3(weight, bias, device, n_align=1):
+        """nn.Conv2d 3x3 weight [Cout, Cin, 3, 3] -> [Cout][kh][kw][Cin_pad64]."""
+        co, ci = weight.shape[0], weight.shape[1]
+        w = weight.detach().permute(0, 2, 3, 1)
+        cip = (ci + 63) // 64 * 64
+        if cip != ci:
+            w = torch.nn.functional.pad(w, (0, cip - ci))
+        w = w.reshape(co, 9 * cip)
+        if co % n_align != 0:
+            npad = (co + n_align - 1) // n_align * n_align
+            w = torch.nn.functional.pad(w, (0, 0, 0, npad - co))
+            if bias is not None:
+                bias = torch.nn.functional.pad(bias.detach(), (0, npad - co))
+        return PackedWeight._finish(w, bias, device, cip, 9)
+
+    @staticmethod
+    def tconv3(weight, bias, device):
+        """nn.Conv3d (3,1,1) weight [Cout, Cin, 3, 1, 1] -> [Cout][kt][Cin]."""
+        co, ci = weight.shape[0], weight.shape[1]
+        w = weight.detach().reshape(co, ci, 3).permute(0, 2, 1).reshape(co, 3 * ci)
+        return PackedWeight._finish(w, bias, device, ci, 3)
+
+
+def gemm(a, pw, out, *, M=None, residual=None, rowvec=None, rows_per_vec=1, geglu=False, alpha=1.0,
+         conv=None, tconv=None):
+    """out[M, N] = epilogue(gather(a) @ pw.w[:N].T). `out` dtype bf16 or float32 selects the output type.
+
+    conv  = dict(IH, IW, OH, OW, stride, pad, ups)   -> 3x3 implicit GEMM over frames of a
+    tconv = dict(T, HW)                               -> 3-tap temporal conv
+    """
+    _rows(a, "a")
+    out_f32 = out.dtype == torch.float32
+    if not out_f32:
+        _rows(out, "out")
+    p = DcGemmParams()
+    p.A, p.W, p.C = a.data_ptr(), pw.w.data_ptr(), out.data_ptr()
+    p.bias = 0 if pw.bias is None else pw.bias.data_ptr()
+    p.rowvec = 0 if rowvec is None else rowvec.data_ptr()
+    p.rowvec_ld = 0 if rowvec is None else rowvec.stride(0)
+    p.rows_per_vec = rows_per_vec
+    p.residual = 0 if residual is None else _rows(residual, "residual").data_ptr()
+    p.ldr = 0 if residual is None else residual.stride(0)
+    p.lda, p.ldc = a.stride(0), out.stride(0)
+    p.M = out.shape[0] if M is None else M
+    p.N, p.K, p.n_pad = pw.N, pw.K, pw.n_pad
+    p.Cin = pw.Cin
+    p.flags = (_hip.DC_GEMM_OUT_F32 if out_f32 else 0) | (_hip.DC_GEMM_GEGLU if geglu else 0)
+    p.alpha = alpha
+    if conv is not None:
+        p.mode = 1
+        p.IH, p.IW, p.OH, p.OW = conv["IH"], conv["IW"], conv["OH"], conv["OW"]
+        p.stride, p.pad, p.ups = conv.get("stride", 1), conv.get("pad", 1), conv.get("ups", 0)
+        if pw.taps != 9 or a.shape[1] < pw.Cin:
+            raise ValueError("conv3x3 weight / activation mismatch")
+    elif tconv is not None:
+        p.mode = 2
+        p.T, p.HW = tconv["T"], tconv["HW"]
+        if pw.taps != 3:
+            raise ValueError("tconv weight mismatch")
+    else:
+        p.mode = 0
+        if a.shape[1] < pw.K:
+            raise ValueError(f"gemm: activation has {a.shape[1]} columns, weight K={pw.K}")
+    n_out = pw.N // 2 if geglu else pw.N
+    if out.shape[1] < n_out:
+        raise ValueError(f"gemm: out has {out.shape[1]} columns, need {n_out}")
+    check(_hip.lib().dc_gemm_conv(C.byref(p), stream_ptr()), "dc_gemm_conv")
+    return out
+
+
+_gn_ws = {}
+
+
+def _gn_workspace(device, nbytes):
+    key = (device.index,)
+    buf = _gn_ws.get(key)
+    if buf is None or buf.numel() * 4 < nbytes:
+        buf = torch.empty((max(nbytes, 1 << 20) + 3) // 4, dtype=torch.float32, device=device)
+        _gn_ws[key] = buf
+    return buf
+
+
+def groupnorm(x, y, gamma, beta, *, groups, n_inst, rows_per_inst, eps, silu):
+    _rows(x, "x"); _rows(y, "y")
+    Cc = gamma.numel()
+    l = _hip.lib()
+    ws = _gn_workspace(x.device, int(l.dc_groupnorm_workspace_bytes(n_inst, groups, rows_per_inst)))
+    check(l.dc_groupnorm(_ptr(x), x.stride(0), _ptr(y), y.stride(0), _ptr(gamma), _ptr(beta), Cc, groups, n_inst,
+                         rows_per_inst, eps, 1 if silu else 0, _ptr(ws), stream_ptr()), "dc_groupnorm")
+    return y
+
+
+def layernorm(x, y, gamma, beta, eps=1e-5):
+    _rows(x, "x"); _rows(y, "y")
+    check(_hip.lib().dc_layernorm(_ptr(x), x.stride(0), _ptr(y), y.stride(0), _ptr(gamma), _ptr(beta), x.shape[0],
+                                  gamma.numel(), eps, stream_ptr()), "dc_layernorm")
+    return y
+
+
+def flash_attn(q, k, v, o, *, batch, heads, Lq, Lk, scale, accumulate=False, acc_scale=1.0):
+    """q/o rows [batch*Lq, >=heads*64]; k/v rows [batch*Lk, ...] (views into a fused qkv buffer are fine)."""
+    for t, n in ((q, "q"), (k, "k"), (v, "v"), (o, "o")):
+        _rows(t, n)
+    check(_hip.lib().dc_flash_attn_d64(_ptr(q), _ptr(k), _ptr(v), _ptr(o), q.stride(0), k.stride(0), v.stride(0),
+                                       o.stride(0), batch, heads, Lq, Lk, Lq, Lk, scale, 1 if accumulate else 0,
+                                       acc_scale, stream_ptr()), "dc_flash_attn_d64")
+    return o
+
+
+def temporal_attn(qkv, o, *, B, T, HW, heads, scale):
+    _rows(qkv, "qkv"); _rows(o, "o")
+    check(_hip.lib().dc_temporal_attn_d64(_ptr(qkv), qkv.stride(0), _ptr(o), o.stride(0), B, T, HW, heads, scale,
+                                          stream_ptr()), "dc_temporal_attn_d64")
+    return o
+
+
+def gemv_small(x, pw, out, *, act_in=0, act_out=0, accumulate=False):
+    """x [M<=8, K] fp32, out [M, N] fp32."""
+    check(_hip.lib().dc_gemv_small(_ptr(x), x.stride(0), _ptr(pw.w), _ptr(pw.bias), _ptr(out), out.stride(0),
+                                   x.shape[0], pw.N, pw.K, act_in, act_out, 1 if accumulate else 0, stream_ptr()),
+          "dc_gemv_small")
+    return out
+
+
+def timestep_embedding(t_table, out, dim, *, t_index=None, t_stride=0, max_period=10000.0):
+    check(_hip.lib().dc_timestep_embedding(_ptr(t_table), _ptr(t_index), t_stride, _ptr(out), out.shape[0], dim,
+                                           max_period, stream_ptr()), "dc_timestep_embedding")
+    return out
+
+
+def pack_latent(x, cc, out, *, B, Cx, Cc, T, HW, nrep=1):
+    check(_hip.lib().dc_pack_latent(_ptr(x), _ptr(cc), _ptr(out), B, Cx, Cc, T, HW, out.stride(0), nrep,
+                                    stream_ptr()), "dc_pack_latent")
+    return out
+
+
+def nchw_to_rows(x, out, *, N, Cc, HW, scale=1.0):
+    check(_hip.lib().dc_nchw_to_rows(_ptr(x), _ptr(out), N, Cc, HW, out.stride(0), scale, stream_ptr()),
+          "dc_nchw_to_rows")
+    return out
+
+
+def rows_to_nchw(rows, y, *, N, Cc, HW, scale=1.0):
+    check(_hip.lib().dc_rows_to_nchw(_ptr(rows), rows.stride(0), 1 if rows.dtype == torch.float32 else 0, _ptr(y),
+                                     N, Cc, HW, scale, stream_ptr()), "dc_rows_to_nchw")
+    return y
+
+
+def copy2d(src, dst, cols=None):
+    _rows(src, "src"); _rows(dst, "dst")
+    cols = src.shape[1] if cols is None else cols
+    check(_hip.lib().dc_copy2d(_ptr(src), src.stride(0), _ptr(dst), dst.stride(0), src.shape[0], cols, stream_ptr()),
+          "dc_copy2d")
+    return dst
+
+
+def add_rows(a, b, y):
+    check(_hip.lib().dc_add_rows(_ptr(a), a.stride(0), _ptr(b), b.stride(0), _ptr(y), y.stride(0), a.shape[0],
+                                 a.shape[1], stream_ptr()), "dc_add_rows")
+    return y
+
+
+def build_context(ctx, out, *, B, T, n_text, L, D):
+    check(_hip.lib().dc_build_context(_ptr(ctx), _ptr(out), B, T, n_text, L, D, stream_ptr()), "dc_build_context")
+    return out
+
+
+def softmax_rows(x, y):
+    check(_hip.lib().dc_softmax_rows(_ptr(x), x.stride(0), _ptr(y), y.stride(0), x.shape[0], x.shape[1],
+                                     stream_ptr()), "dc_softmax_rows")
+    return y
+
+
+def vae_sample(moments, noise, z, *, N, zc, HW, scale):
+    check(_hip.lib().dc_vae_sample(_ptr(moments), moments.stride(0), _ptr(noise), _ptr(z), N, zc, HW, scale,
+                                   stream_ptr()), "dc_vae_sample")
+    return z
+
+
+def ddim_step(tables, e_cond, e_uncond, e_img, x, noise, x_prev, pred_x0, workspace, *, B, Cc, THW, index=0,
+              step_index=None, v_param=False, cfg_scale=1.0, cfg_img=1.0, guidance_rescale=0.0, temperature=1.0):
+    """tables: dict of fp32 device vectors (a_t, a_prev, sigma_t, sqrt_one_minus_at[, sqrt_acp_t, sqrt_1macp_t,
+    scale_ratio]) indexed by the DDIM index."""
+    p = DcDdimParams()
+    for k in ("a_t", "a_prev", "sigma_t", "sqrt_one_minus_at", "sqrt_acp_t", "sqrt_1macp_t", "scale_ratio"):
+        t = tables.get(k)
+        setattr(p, k, 0 if t is None else t.data_ptr())
+    p.step_index = 0 if step_index is None else step_index.data_ptr()
+    p.index, p.v_param = index, 1 if v_param else 0
+    p.cfg_scale, p.cfg_img, p.guidance_rescale, p.temperature = cfg_scale, cfg_img, guidance_rescale, temperature
+    check(_hip.lib().dc_ddim_step(C.byref(p), _ptr(e_cond), _ptr(e_uncond), _ptr(e_img), e_cond.stride(0), _ptr(x),
+                                  _ptr(noise), _ptr(x_prev), _ptr(pred_x0), B, Cc, THW, _ptr(workspace),
+                                  stream_ptr()), "dc_ddim_step")
+    return x_prev, pred_x0
+
+
+def advance_counter(counter):
+    check(_hip.lib().dc_advance_counter(_ptr(counter), stream_ptr()), "dc_advance_counter")
+
+
+class DeviceGraph:
+    """hipGraph capture/replay of a block of dc_* calls issued on a private stream (runtime.hip)."""
+
+    def __init__(self):
+        l = _hip.lib()
+        s = C.c_void_p()
+        check(l.dc_stream_create(C.byref(s)), "dc_stream_create")
+        self._stream = s
+        self.torch_stream = torch.cuda.ExternalStream(s.value)
+        self._exec = None
+
+    def capture(self, fn):
+        l = _hip.lib()
+        torch.cuda.synchronize()
+        with torch.cuda.stream(self.torch_stream):
+            check(l.dc_graph_begin_capture(self._stream), "dc_graph_begin_capture")
+            try:
+                fn()
+            finally:
+                ex = C.c_void_p()
+                code = l.dc_graph_end_capture(self._stream, C.byref(ex))
+            check(code, "dc_graph_end_capture")
+        self._exec = ex
+        return self
+
+    def launch(self):
+        check(_hip.lib().dc_graph_launch(self._exec, self._stream), "dc_graph_launch")
+
+    def sync(self):
+        check(_hip.lib().dc_stream_sync(self._stream), "dc_stream_sync")
+
+    def __del__(self):
+        try:
+            l = _hip.lib()
+            if self._exec is not None:
+                l.dc_graph_destroy(self._exec)
+            l.dc_stream_destroy(self._stream)
+        except Exception:
+            pass

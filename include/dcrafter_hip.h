@@ -1,0 +1,184 @@
+/* dcrafter_hip.h — C ABI of libdcrafter_hip.so: the MI355X (gfx950) device path of the DynamiCrafter denoising
+ * loop (DDIM sampler -> 3D UNet forward -> AutoencoderKL encode/decode).
+ *
+ * The reference (87003697/DynamiCrafter) contains no native code; its "FFI" for this path is PyTorch's ATen
+ * dispatch underneath the lvdm Python classes. Each entry point below therefore names the reference call site
+ * (path:line under the reference root) whose ATen ops it replaces. The Python classes in
+ * the dynamicrafter_amd/lvdm package keep the reference's constructor/forward signatures and call these through ctypes
+ * (INTEGRATION.md shows the binding).
+ *
+ * Conventions
+ *   - every function returns 0 on success, a hipError_t (>0) from the launch, or a DC_ERR_* (<0) for bad arguments;
+ *     nothing throws, nothing allocates, nothing synchronises: all work is enqueued on `stream` (a hipStream_t
+ *     passed as void*), so every call is hipGraph-capturable.
+ *   - device pointers only. bf16 = raw uint16 bits. Activations are channels-last rows: [rows, C] with
+ *     row = ((b*T + t)*H + y)*W + x and `ld*` the row stride in elements.
+ *   - weights are repacked once by the host: Linear [N][K] as in torch; conv3x3 [Cout][kh][kw][Cin];
+ *     temporal conv [Cout][kt][Cin]; N zero-padded to a multiple of 128 rows; biases/affine params fp32.
+ */
+#ifndef DCRAFTER_HIP_H
+#define DCRAFTER_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DC_ERR_SHAPE (-1)   /* unsupported / inconsistent shape or stride */
+#define DC_ERR_ARG   (-2)   /* null pointer or bad enum */
+
+#define DC_GEMM_OUT_F32 1   /* C is float32 (no residual) */
+#define DC_GEMM_GEGLU   2   /* W = [value half ; gate half] (N = 2*Nout): C = (xW_v+b_v) * gelu_erf(xW_g+b_g) */
+
+typedef struct DcGemmParams {
+    const uint16_t* A;        /* activation rows (bf16) */
+    const uint16_t* W;        /* weights [n_pad][K] (bf16), rows >= N are zero */
+    void* C;                  /* output rows, bf16 or f32 (flags) */
+    const float* bias;        /* [N] or NULL */
+    const float* rowvec;      /* optional broadcast add: rowvec[(m / rows_per_vec) * rowvec_ld + n] (timestep-embedding add) */
+    const uint16_t* residual; /* optional bf16 residual rows, added after everything else */
+    int lda, ldc, ldr, rowvec_ld;
+    int rows_per_vec;
+    int M, N, K, n_pad;
+    int mode;                 /* 0 plain, 1 conv2d 3x3, 2 temporal conv 3x1x1 */
+    int Cin;                  /* channels per tap (mode 1/2): K = taps*Cin */
+    int IH, IW, OH, OW;       /* mode 1: source frame size (before the fused upsample) and output frame size */
+    int stride, pad, ups;     /* mode 1: stride 1|2, top/left pad (bottom/right implied by OH/OW), ups=1 -> nearest x2 of the source */
+    int T, HW;                /* mode 2: frames per clip, rows per frame */
+    int flags;
+    float alpha;              /* output scale applied last (before the residual add) */
+} DcGemmParams;
+
+/* Linear / 1x1 conv / conv2d 3x3 / Conv3d(3,1,1) on MFMA.
+ * replaces: nn.Linear  lvdm/modules/attention.py:53-57,75-76,269,290,336,362,418,438
+ *           nn.Conv2d  lvdm/modules/networks/openaimodel3d.py:68,96,154,179,187,386,545 (+F.interpolate :103 when ups=1)
+ *           nn.Conv3d  lvdm/modules/networks/openaimodel3d.py:255-266
+ *           nn.Conv2d  lvdm/modules/networks/ae_modules.py:31-50,96-106,117-126,161-186 ; lvdm/models/autoencoder.py:34-35
+ *           GEGLU      lvdm/modules/attention.py:415-422 (DC_GEMM_GEGLU) */
+int dc_gemm_conv(const DcGemmParams* p, void* stream);
+
+/* GroupNorm (+ optional SiLU) over channels-last rows; statistics in fp32.
+ * One "instance" = rows_per_inst consecutive rows sharing statistics: H*W for the 4-D norms, T*H*W for the 5-D
+ * norms of TemporalConvBlock / TemporalTransformer.
+ * replaces: GroupNormSpecific lvdm/basics.py:76-87; nn.GroupNorm openaimodel3d.py:256-265, attention.py:265,331;
+ *           Normalize + nonlinearity lvdm/modules/networks/ae_modules.py:10-16
+ * workspace: dc_groupnorm_workspace_bytes() bytes of device scratch. */
+int dc_groupnorm(const uint16_t* x, int ldx, uint16_t* y, int ldy, const float* gamma, const float* beta,
+                 int C, int groups, int n_inst, int rows_per_inst, float eps, int silu,
+                 float* workspace, void* stream);
+int64_t dc_groupnorm_workspace_bytes(int n_inst, int groups, int rows_per_inst);
+
+/* LayerNorm over the last dim of [rows, C]. replaces nn.LayerNorm lvdm/modules/attention.py:225-227 */
+int dc_layernorm(const uint16_t* x, int ldx, uint16_t* y, int ldy, const float* gamma, const float* beta,
+                 int rows, int C, float eps, void* stream);
+
+/* softmax(q k^T * scale) v, head_dim 64, flash-style (no score matrix in HBM).
+ * q rows: [batch][Lq] at q + (b*q_bstride + i)*ldq + h*64 ; k/v rows: [batch][Lk] likewise with kv_bstride.
+ * accumulate != 0: o += acc_scale * result (image cross-attention branch), else o = result.
+ * replaces: CrossAttention.forward core lvdm/modules/attention.py:101-142 (einsum/softmax/einsum, and the
+ *           xformers path :166-207) for spatial self-attention and text / image cross-attention. */
+int dc_flash_attn_d64(const uint16_t* q, const uint16_t* k, const uint16_t* v, uint16_t* o,
+                      int ldq, int ldk, int ldv, int ldo, int batch, int heads, int Lq, int Lk,
+                      int64_t q_bstride, int64_t kv_bstride, float scale, int accumulate, float acc_scale,
+                      void* stream);
+
+/* Temporal self-attention over T <= 16 frames, head_dim 64: for every (clip b, position p, head h) the T rows
+ * (b, t, p) attend to each other. qkv rows are [q | k | v] (3*heads*64 wide, row stride ld).
+ * replaces: CrossAttention.forward lvdm/modules/attention.py:81-144 as used by TemporalTransformer :365-412. */
+int dc_temporal_attn_d64(const uint16_t* qkv, int ld, uint16_t* o, int ldo, int B, int T, int HW, int heads,
+                         float scale, void* stream);
+
+/* out[m][n] = act_out( bias[n] + sum_k act_in(in[m][k]) * W[n][k] ), m < 8; in/out fp32, W bf16.
+ * act: 0 none, 1 SiLU. accumulate: out += result.
+ * replaces: time_embed / fps_embedding MLPs openaimodel3d.py:370-382,551,575 and ResBlock emb_layers :168-174,219 */
+int dc_gemv_small(const float* in, int ld_in, const uint16_t* W, const float* bias, float* out, int ld_out,
+                  int M, int N, int K, int act_in, int act_out, int accumulate, void* stream);
+
+/* Sinusoidal embedding: out[b][0:half]=cos(t_b*f_i), out[b][half:]=sin(t_b*f_i), f_i=exp(-ln(max_period)*i/half).
+ * t is read from device memory: t_table[t_index[0]*t_stride + b] if t_index != NULL else t_table[b].
+ * replaces: timestep_embedding lvdm/models/utils_diffusion.py:8-28 */
+int dc_timestep_embedding(const int64_t* t_table, const int32_t* t_index, int t_stride, float* out, int B, int dim,
+                          float max_period, void* stream);
+
+/* UNet input assembly: cat([x, c_concat], dim=1) of [B,Cx,T,H,W] + [B,Cc,T,H,W] fp32 tensors -> channels-last
+ * bf16 rows [nrep*B*T*H*W, c_pad] (channels >= Cx+Cc zeroed); the batch is written nrep times (nrep=2 serves
+ * the cond/uncond pair of classifier-free guidance from one latent).
+ * replaces: torch.cat ddpm3d.py:1256 + rearrange openaimodel3d.py:566 */
+int dc_pack_latent(const float* x, const float* cc, uint16_t* out, int B, int Cx, int Cc, int T, int HW,
+                   int c_pad, int nrep, void* stream);
+
+/* Generic layout helpers (channels-last bf16 <-> NCHW fp32), used at the AutoencoderKL boundary.
+ * nchw_to_rows: x[N][C][HW] fp32 -> rows[N*HW][c_pad] bf16 (scaled by `scale`, pad channels zero)
+ * rows_to_nchw: rows[N*HW][ld] (bf16 or f32) -> y[N][C][HW] fp32 */
+int dc_nchw_to_rows(const float* x, uint16_t* out, int N, int C, int HW, int c_pad, float scale, void* stream);
+int dc_rows_to_nchw(const void* rows, int ld, int rows_f32, float* y, int N, int C, int HW, float scale, void* stream);
+
+/* 2-D strided copy of bf16 rows (skip-connection concat: torch.cat openaimodel3d.py:596). cols % 8 == 0. */
+int dc_copy2d(const uint16_t* src, int lds, uint16_t* dst, int ldd, int rows, int cols, void* stream);
+
+/* Per-frame context assembly: context [B, 77 + T*L, D] fp32 -> [B*T, 77+L, D] bf16 where frame (b,t) gets the
+ * 77 text tokens of b followed by image tokens t*L..t*L+L-1. replaces openaimodel3d.py:555-562 */
+int dc_build_context(const float* ctx, uint16_t* out, int B, int T, int n_text, int L, int D, void* stream);
+
+/* Row softmax fp32 -> bf16 (AutoencoderKL mid attention, ae_modules.py:68). */
+int dc_softmax_rows(const float* x, int ldx, uint16_t* y, int ldy, int rows, int cols, void* stream);
+
+/* y = a + b elementwise on bf16 rows (AE residual adds where no GEMM epilogue is available). */
+int dc_add_rows(const uint16_t* a, int lda, const uint16_t* b, int ldb, uint16_t* y, int ldy, int rows, int cols,
+                void* stream);
+
+/* DiagonalGaussianDistribution.sample x scale_factor: moments rows [N*HW][ld] (mean | logvar, zc channels each)
+ * -> z[N][zc][HW] fp32 = scale * (mean + exp(0.5*clamp(logvar,-30,20)) * noise[N][zc][HW]); noise NULL -> mode().
+ * replaces lvdm/distributions.py:25-40 + ddpm3d.py:611-618 */
+int dc_vae_sample(const uint16_t* moments, int ld, const float* noise, float* z, int N, int zc, int HW,
+                  float scale, void* stream);
+
+typedef struct DcDdimParams {
+    /* per-step scalar tables, indexed by step_index[0] (device) when step_index != NULL, else by `index` */
+    const float* a_t;            /* ddim_alphas[index]            (fp32 as torch.full casts them, ddim.py:251) */
+    const float* a_prev;         /* ddim_alphas_prev[index] */
+    const float* sigma_t;        /* ddim_sigmas[index] */
+    const float* sqrt_one_minus_at;
+    const float* sqrt_acp_t;     /* model.sqrt_alphas_cumprod[t]           (v-param, ddpm3d.py:239-251) */
+    const float* sqrt_1macp_t;   /* model.sqrt_one_minus_alphas_cumprod[t] */
+    const float* scale_ratio;    /* ddim_scale_arr_prev[index]/ddim_scale_arr[index] or NULL (ddim.py:262-266) */
+    const int32_t* step_index;   /* device counter or NULL */
+    int index;
+    int v_param;                 /* parameterization == "v" */
+    float cfg_scale;             /* unconditional_guidance_scale; e_uncond may be NULL when 1.0 */
+    float cfg_img;               /* 3-branch CFG (ddim_multiplecond.py:234); used when e_img != NULL */
+    float guidance_rescale;      /* 0 -> off */
+    float temperature;
+} DcDdimParams;
+
+/* One DDIM update for B clips. e_* are the UNet outputs as channels-last fp32 rows [B*T*HW, ld_e] (first C
+ * channels valid); x, noise, x_prev, pred_x0 are [B, C, T*HW] fp32 (the reference's NCTHW layout).
+ * workspace: >= 16 * B * 256 floats.
+ * replaces: p_sample_ddim lvdm/models/samplers/ddim.py:226-277 + rescale_noise_cfg utils_diffusion.py:147-157 */
+int dc_ddim_step(const DcDdimParams* p, const float* e_cond, const float* e_uncond, const float* e_img, int ld_e,
+                 const float* x, const float* noise, float* x_prev, float* pred_x0, int B, int C, int THW,
+                 float* workspace, void* stream);
+
+/* step_index[0] += 1 (device-side loop counter for the graph-captured sampler). */
+int dc_advance_counter(int32_t* counter, void* stream);
+
+/* ---- stream / hipGraph plumbing (one capture per sampler configuration; replayed once per DDIM step) ---- */
+int dc_stream_create(void** stream_out);
+int dc_stream_destroy(void* stream);
+int dc_stream_sync(void* stream);
+int dc_graph_begin_capture(void* stream);
+int dc_graph_end_capture(void* stream, void** graph_exec_out);
+int dc_graph_launch(void* graph_exec, void* stream);
+int dc_graph_destroy(void* graph_exec);
+/* HIP-event timing on an arbitrary stream (bench.py roofline leg) */
+int dc_event_create(void** ev_out);
+int dc_event_record(void* ev, void* stream);
+int dc_event_elapsed_ms(void* ev_start, void* ev_stop, float* ms_out); /* synchronises on ev_stop */
+int dc_event_destroy(void* ev);
+
+const char* dc_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,269 @@
+"""Per-kernel parity: every HIP kernel of the C ABI against a plain PyTorch fp32 statement of the same op
+(inputs rounded to bf16 first, so the comparison isolates the kernel's own arithmetic: fp32 accumulate and one
+bf16 rounding of the output).  Tolerances: rel-L2 <= 4e-3 for bf16 outputs of O(1) data (bf16 has 8 significant
+bits: rounding alone gives ~1.7e-3), 1e-5 for fp32 outputs of elementwise kernels."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+def rel_l2(a, b):
+    a = a.float().cpu(); b = b.float().cpu()
+    return (a - b).norm().item() / max(b.norm().item(), 1e-12)
+
+
+def bf(x):
+    return x.to(torch.bfloat16)
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from dynamicrafter_amd import ops as _ops
+    return _ops
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 320, 320), (130, 640, 64), (1000, 448, 192), (77, 64, 1024), (513, 4, 128)])
+def test_gemm_plain(ops, M, N, K):
+    x = bf(rnd(M, K, seed=1)); w = rnd(N, K, seed=2, scale=K ** -0.5); b = rnd(N, seed=3)
+    pw = ops.PackedWeight.linear(w, b, DEV)
+    out = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+    ops.gemm(x.to(DEV), pw, out)
+    ref = x.float() @ bf(w).float().t() + b
+    assert rel_l2(out, ref) < 4e-3
+    # fp32 output + alpha
+    out32 = torch.empty(M, N, dtype=torch.float32, device=DEV)
+    ops.gemm(x.to(DEV), pw, out32, alpha=0.5)
+    assert rel_l2(out32, 0.5 * ref) < 1e-5 + 1e-6
+
+
+def test_gemm_epilogues(ops):
+    M, N, K = 384, 320, 640
+    x = bf(rnd(M, K, seed=1)); w = rnd(N, K, seed=2, scale=K ** -0.5); b = rnd(N, seed=3)
+    res = bf(rnd(M, N, seed=4)); rv = rnd(3, N, seed=5)
+    pw = ops.PackedWeight.linear(w, b, DEV)
+    out = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+    ops.gemm(x.to(DEV), pw, out, residual=res.to(DEV), rowvec=rv.to(DEV), rows_per_vec=128)
+    ref = x.float() @ bf(w).float().t() + b + rv.repeat_interleave(128, 0)
+    ref = bf(ref).float() + res.float()   # kernel rounds to bf16 before the residual add
+    assert rel_l2(out, ref) < 4e-3
+    # strided input / output views (lda, ldc > width)
+    big_in = torch.zeros(M, K + 64, dtype=torch.bfloat16, device=DEV); big_in[:, 32 - 32:K] = x.to(DEV)
+    big_out = torch.zeros(M, N + 320, dtype=torch.bfloat16, device=DEV)
+    ops.gemm(big_in[:, :K], pw, big_out[:, 320:])
+    assert rel_l2(big_out[:, 320:], x.float() @ bf(w).float().t() + b) < 4e-3
+    assert big_out[:, :320].abs().max().item() == 0
+
+
+def test_gemm_geglu(ops):
+    M, dim, inner = 200, 128, 512
+    x = bf(rnd(M, dim, seed=1)); w = rnd(2 * inner, dim, seed=2, scale=dim ** -0.5); b = rnd(2 * inner, seed=3, scale=0.1)
+    pw = ops.PackedWeight.linear(w, b, DEV)
+    out = torch.empty(M, inner, dtype=torch.bfloat16, device=DEV)
+    ops.gemm(x.to(DEV), pw, out, geglu=True)
+    h = x.float() @ bf(w).float().t() + b
+    val, gate = h.chunk(2, dim=-1)
+    ref = val * F.gelu(gate)
+    assert rel_l2(out, ref) < 4e-3
+
+
+@pytest.mark.parametrize("cfg", [
+    dict(n=3, C=64, Co=128, H=9, W=11, stride=1, pad=1, ups=0),
+    dict(n=2, C=128, Co=320, H=12, W=16, stride=2, pad=1, ups=0),      # UNet Downsample
+    dict(n=2, C=64, Co=64, H=12, W=10, stride=2, pad=0, ups=0),        # AE Downsample: pad (0,1,0,1)
+    dict(n=2, C=128, Co=192, H=6, W=7, stride=1, pad=1, ups=1),        # nearest x2 + conv
+    dict(n=2, C=8, Co=64, H=8, W=8, stride=1, pad=1, ups=0),           # Cin padded to 64
+])
+def test_conv3x3(ops, cfg):
+    n, Cc, Co, H, W = cfg["n"], cfg["C"], cfg["Co"], cfg["H"], cfg["W"]
+    x = bf(rnd(n, Cc, H, W, seed=1)); w = rnd(Co, Cc, 3, 3, seed=2, scale=(9 * Cc) ** -0.5); b = rnd(Co, seed=3)
+    xr = x.float()
+    if cfg["ups"]:
+        xr = F.interpolate(xr, scale_factor=2, mode="nearest")
+    if cfg["stride"] == 2 and cfg["pad"] == 0:
+        xr = F.pad(xr, (0, 1, 0, 1))
+        ref = F.conv2d(xr, bf(w).float(), b, stride=2, padding=0)
+    else:
+        ref = F.conv2d(xr, bf(w).float(), b, stride=cfg["stride"], padding=cfg["pad"])
+    OH, OW = ref.shape[2], ref.shape[3]
+    pw = ops.PackedWeight.conv3x3(w, b, DEV)
+    cp = pw.Cin
+    rows = torch.zeros(n * H * W, cp, dtype=torch.bfloat16, device=DEV)
+    rows[:, :Cc] = x.permute(0, 2, 3, 1).reshape(-1, Cc).to(DEV)
+    out = torch.empty(n * OH * OW, Co, dtype=torch.bfloat16, device=DEV)
+    ops.gemm(rows, pw, out, conv=dict(IH=H, IW=W, OH=OH, OW=OW, stride=cfg["stride"], pad=cfg["pad"], ups=cfg["ups"]))
+    got = out.float().cpu().reshape(n, OH, OW, Co).permute(0, 3, 1, 2)
+    assert rel_l2(got, ref) < 4e-3
+
+
+def test_tconv3(ops):
+    B, T, HW, Cc = 2, 5, 37, 128
+    x = bf(rnd(B, Cc, T, HW, 1, seed=1)); w = rnd(Cc, Cc, 3, 1, 1, seed=2, scale=(3 * Cc) ** -0.5); b = rnd(Cc, seed=3)
+    ref = F.conv3d(x.float(), bf(w).float(), b, padding=(1, 0, 0))
+    pw = ops.PackedWeight.tconv3(w, b, DEV)
+    rows = x.permute(0, 2, 3, 4, 1).reshape(-1, Cc).contiguous().to(DEV)
+    out = torch.empty_like(rows)
+    ops.gemm(rows, pw, out, tconv=dict(T=T, HW=HW))
+    got = out.float().cpu().reshape(B, T, HW, 1, Cc).permute(0, 4, 1, 2, 3)
+    assert rel_l2(got, ref) < 4e-3
+
+
+@pytest.mark.parametrize("Cc,n_inst,rpi,silu,eps", [(320, 4, 200, True, 1e-5), (64, 2, 33, False, 1e-6),
+                                                    (2560, 2, 144, True, 1e-5), (128, 1, 5000, True, 1e-6),
+                                                    (960, 3, 64, True, 1e-5)])
+def test_groupnorm(ops, Cc, n_inst, rpi, silu, eps):
+    x = bf(rnd(n_inst * rpi, Cc, seed=1) * 2 + 0.5)
+    g = 1 + 0.2 * rnd(Cc, seed=2); b = 0.3 * rnd(Cc, seed=3)
+    y = torch.empty_like(x, device=DEV)
+    ops.groupnorm(x.to(DEV), y, g.to(DEV), b.to(DEV), groups=32, n_inst=n_inst, rows_per_inst=rpi, eps=eps, silu=silu)
+    xr = x.float().reshape(n_inst, rpi, Cc).permute(0, 2, 1)     # [n, C, rows]
+    ref = F.group_norm(xr, 32, g, b, eps)
+    if silu:
+        ref = F.silu(ref)
+    ref = ref.permute(0, 2, 1).reshape(-1, Cc)
+    assert rel_l2(y, ref) < 4e-3
+
+
+@pytest.mark.parametrize("Cc", [320, 512, 640, 1280, 64])
+def test_layernorm(ops, Cc):
+    R = 301
+    x = bf(rnd(R, Cc, seed=1) * 3 - 1)
+    g = 1 + 0.2 * rnd(Cc, seed=2); b = 0.3 * rnd(Cc, seed=3)
+    y = torch.empty_like(x, device=DEV)
+    ops.layernorm(x.to(DEV), y, g.to(DEV), b.to(DEV), 1e-5)
+    assert rel_l2(y, F.layer_norm(x.float(), (Cc,), g, b, 1e-5)) < 4e-3
+
+
+def _attn_ref(q, k, v, heads, scale):
+    # q [B, Lq, h*64], k/v [B, Lk, h*64] -> [B, Lq, h*64]
+    B, Lq, _ = q.shape
+    qh = q.reshape(B, Lq, heads, 64).transpose(1, 2)
+    kh = k.reshape(B, -1, heads, 64).transpose(1, 2)
+    vh = v.reshape(B, -1, heads, 64).transpose(1, 2)
+    p = torch.softmax(qh @ kh.transpose(-1, -2) * scale, dim=-1)
+    return (p @ vh).transpose(1, 2).reshape(B, Lq, heads * 64)
+
+
+@pytest.mark.parametrize("B,heads,Lq,Lk", [(2, 5, 144, 144), (1, 2, 300, 77), (3, 1, 64, 16), (1, 3, 1000, 1000),
+                                           (2, 2, 40, 40)])
+def test_flash_attn(ops, B, heads, Lq, Lk):
+    Cc = heads * 64
+    q = bf(rnd(B, Lq, Cc, seed=1)); k = bf(rnd(B, Lk, Cc, seed=2)); v = bf(rnd(B, Lk, Cc, seed=3))
+    o = torch.zeros(B * Lq, Cc, dtype=torch.bfloat16, device=DEV)
+    ops.flash_attn(q.reshape(-1, Cc).to(DEV), k.reshape(-1, Cc).to(DEV), v.reshape(-1, Cc).to(DEV), o,
+                   batch=B, heads=heads, Lq=Lq, Lk=Lk, scale=0.125)
+    ref = _attn_ref(q.float(), k.float(), v.float(), heads, 0.125).reshape(-1, Cc)
+    assert rel_l2(o, ref) < 6e-3
+    # accumulate epilogue: o += 0.5 * attn
+    ops.flash_attn(q.reshape(-1, Cc).to(DEV), k.reshape(-1, Cc).to(DEV), v.reshape(-1, Cc).to(DEV), o,
+                   batch=B, heads=heads, Lq=Lq, Lk=Lk, scale=0.125, accumulate=True, acc_scale=0.5)
+    assert rel_l2(o, 1.5 * ref) < 8e-3
+
+
+def test_flash_attn_fused_qkv_and_spike(ops):
+    """q/k/v as column slices of one [rows, 3C] buffer; a spiked key forces a large running-max jump."""
+    B, heads, L = 2, 2, 200
+    Cc = heads * 64
+    qkv = rnd(B * L, 3 * Cc, seed=5)
+    qkv[130, Cc:2 * Cc] *= 12.0
+    qkv = bf(qkv)
+    d = qkv.to(DEV)
+    o = torch.empty(B * L, Cc, dtype=torch.bfloat16, device=DEV)
+    ops.flash_attn(d[:, :Cc], d[:, Cc:2 * Cc], d[:, 2 * Cc:], o, batch=B, heads=heads, Lq=L, Lk=L, scale=0.125)
+    f = qkv.float().reshape(B, L, 3 * Cc)
+    ref = _attn_ref(f[..., :Cc], f[..., Cc:2 * Cc], f[..., 2 * Cc:], heads, 0.125).reshape(-1, Cc)
+    assert rel_l2(o, ref) < 6e-3
+
+
+@pytest.mark.parametrize("B,T,HW,heads", [(2, 16, 50, 5), (1, 16, 7, 8), (1, 4, 33, 2)])
+def test_temporal_attn(ops, B, T, HW, heads):
+    Cc = heads * 64
+    qkv = bf(rnd(B * T * HW, 3 * Cc, seed=7))
+    o = torch.zeros(B * T * HW, Cc, dtype=torch.bfloat16, device=DEV)
+    ops.temporal_attn(qkv.to(DEV), o, B=B, T=T, HW=HW, heads=heads, scale=0.125)
+    f = qkv.float().reshape(B, T, HW, 3 * Cc).permute(0, 2, 1, 3).reshape(B * HW, T, 3 * Cc)
+    ref = _attn_ref(f[..., :Cc], f[..., Cc:2 * Cc], f[..., 2 * Cc:], heads, 0.125)
+    ref = ref.reshape(B, HW, T, Cc).permute(0, 2, 1, 3).reshape(-1, Cc)
+    assert rel_l2(o, ref) < 6e-3
+
+
+def test_gemv_and_embedding(ops):
+    M, K, N = 2, 320, 1280
+    t = torch.tensor([999, 17], dtype=torch.int64)
+    emb = torch.empty(M, K, dtype=torch.float32, device=DEV)
+    ops.timestep_embedding(t.to(DEV), emb, K)
+    half = K // 2
+    freqs = torch.exp(-math.log(10000) * torch.arange(half, dtype=torch.float32) / half)
+    args = t[:, None].float() * freqs[None]
+    ref_e = torch.cat([torch.cos(args), torch.sin(args)], -1)
+    assert (emb.cpu() - ref_e).abs().max().item() < 2e-4     # fp32 cos/sin of arguments up to 999
+    w = rnd(N, K, seed=1, scale=K ** -0.5); b = rnd(N, seed=2)
+    pw = ops.PackedWeight.linear(w, b, DEV)
+    out = torch.empty(M, N, dtype=torch.float32, device=DEV)
+    ops.gemv_small(emb, pw, out, act_in=0, act_out=1)
+    ref = F.silu(emb.cpu() @ bf(w).float().t() + b)
+    assert rel_l2(out, ref) < 1e-5
+    out2 = out.clone()
+    ops.gemv_small(emb, pw, out2, act_in=1, act_out=0, accumulate=True)
+    ref2 = ref + F.silu(emb.cpu()) @ bf(w).float().t() + b
+    assert rel_l2(out2, ref2) < 1e-5
+
+
+def test_layout_kernels(ops):
+    B, Cx, Cc, T, HW = 2, 4, 4, 3, 20
+    x = rnd(B, Cx, T, HW, seed=1); cc = rnd(B, Cc, T, HW, seed=2)
+    out = torch.full((2 * B * T * HW, 64), 7.0, dtype=torch.bfloat16, device=DEV)
+    ops.pack_latent(x.to(DEV), cc.to(DEV), out, B=B, Cx=Cx, Cc=Cc, T=T, HW=HW, nrep=2)
+    ref = torch.cat([x, cc], 1).permute(0, 2, 3, 1).reshape(-1, Cx + Cc)
+    got = out.float().cpu()
+    assert torch.equal(got[:B * T * HW, :8], bf(ref).float()) and torch.equal(got[B * T * HW:, :8], bf(ref).float())
+    assert got[:, 8:].abs().max().item() == 0
+    # nchw <-> rows
+    img = rnd(3, 3, 30, seed=3)
+    rows = torch.empty(3 * 30, 64, dtype=torch.bfloat16, device=DEV)
+    ops.nchw_to_rows(img.to(DEV), rows, N=3, Cc=3, HW=30, scale=2.0)
+    assert torch.equal(rows[:, :3].float().cpu(), bf(2 * img.permute(0, 2, 1).reshape(-1, 3)).float())
+    back = torch.empty(3, 3, 30, dtype=torch.float32, device=DEV)
+    ops.rows_to_nchw(rows, back, N=3, Cc=3, HW=30, scale=0.5)
+    assert torch.equal(back.cpu(), bf(2 * img).float() * 0.5)
+    # copy2d into a concat buffer, add_rows
+    a = bf(rnd(50, 64, seed=4)); b2 = bf(rnd(50, 128, seed=5))
+    cat = torch.empty(50, 192, dtype=torch.bfloat16, device=DEV)
+    ops.copy2d(a.to(DEV), cat[:, :64]); ops.copy2d(b2.to(DEV), cat[:, 64:])
+    assert torch.equal(cat.cpu(), torch.cat([a, b2], 1))
+    s = torch.empty(50, 64, dtype=torch.bfloat16, device=DEV)
+    ops.add_rows(a.to(DEV), a.to(DEV), s)
+    assert torch.equal(s.cpu(), bf(a.float() * 2))
+    # context assembly
+    Bc, Tc, L, D = 2, 3, 4, 64
+    ctx = rnd(Bc, 77 + Tc * L, D, seed=6)
+    outc = torch.empty(Bc * Tc, 77 + L, D, dtype=torch.bfloat16, device=DEV)
+    ops.build_context(ctx.to(DEV), outc, B=Bc, T=Tc, n_text=77, L=L, D=D)
+    text = ctx[:, :77].repeat_interleave(Tc, 0)
+    imgc = ctx[:, 77:].reshape(Bc, Tc, L, D).reshape(Bc * Tc, L, D)
+    assert torch.equal(outc.cpu(), bf(torch.cat([text, imgc], 1)))
+
+
+def test_softmax_and_vae_sample(ops):
+    x = rnd(37, 1000, seed=1) * 4
+    y = torch.empty(37, 1000, dtype=torch.bfloat16, device=DEV)
+    ops.softmax_rows(x.to(DEV), y)
+    assert rel_l2(y, torch.softmax(x, -1)) < 4e-3
+    N, zc, HW = 2, 4, 50
+    mom = bf(rnd(N * HW, 8, seed=2) * 3); noise = rnd(N, zc, HW, seed=3)
+    z = torch.empty(N, zc, HW, dtype=torch.float32, device=DEV)
+    ops.vae_sample(mom.to(DEV), noise.to(DEV), z, N=N, zc=zc, HW=HW, scale=0.18215)
+    m = mom.float().reshape(N, HW, 8).permute(0, 2, 1)
+    mean, logvar = m[:, :4], torch.clamp(m[:, 4:], -30, 20)
+    ref = 0.18215 * (mean + torch.exp(0.5 * logvar) * noise)
+    assert rel_l2(z, ref) < 1e-5
