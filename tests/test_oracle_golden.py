@@ -1,0 +1,168 @@
+"""Pin the oracle (oracle/*.py, CPU fp32 restatement) against outputs of the reference's own modules
+(tests/golden/*.npz, produced by tests/golden/make_golden.py in the build container). CPU only."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import yaml
+
+from oracle import ddim as oddim
+from oracle import unet as ounet
+from oracle import vae as ovae
+from oracle.weights import fill_state_dict
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def load(name):
+    return np.load(os.path.join(G, name + ".npz"), allow_pickle=False)
+
+
+def T(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+def maxrel(a, b):
+    a = torch.as_tensor(a).double(); b = torch.as_tensor(b).double()
+    return ((a - b).abs().max() / b.abs().max().clamp_min(1e-30)).item()
+
+
+@pytest.mark.parametrize("tag", ["v1024", "v256"])
+def test_unet_tiny_matches_reference(tag):
+    g = load(f"unet_tiny_{tag}")
+    params = yaml.safe_load(str(g["yaml_params"]))
+    cfg = ounet.UNetCfg.from_params(params)
+    shapes = ounet.unet_param_shapes(cfg)
+    assert sorted(shapes) == [str(s) for s in g["param_names"]]       # checkpoint-key compatibility
+    sd = fill_state_dict(shapes, seed=11)
+    y = ounet.unet_forward(sd, cfg, T(g["x"]), T(g["timesteps"]), T(g["context"]), T(g["fs"]))
+    assert maxrel(y, g["y"]) < 2e-5
+    y2 = ounet.unet_forward(sd, cfg, T(g["x"]), T(g["timesteps"]), T(g["context"]), None)
+    assert maxrel(y2, g["y_default_fs"]) < 2e-5
+    assert float(np.abs(g["y"]).max()) > 1e-2                            # not the degenerate all-zero output
+
+
+@pytest.mark.parametrize("tag", ["tiny", "full"])
+def test_ae_matches_reference(tag):
+    g = load(f"ae_{tag}")
+    dd = yaml.safe_load(str(g["yaml_params"]))
+    cfg = ovae.AECfg.from_params(dd, embed_dim=4)
+    shapes = ovae.ae_param_shapes(cfg)
+    assert sorted(shapes) == [str(s) for s in g["param_names"]]
+    sd = fill_state_dict(shapes, seed=13)
+    mom = ovae.encode_moments(sd, cfg, T(g["img"]))
+    assert maxrel(mom, g["moments"]) < 2e-5
+    z = ovae.posterior_sample(mom, T(g["noise"]))
+    assert maxrel(z, g["z"]) < 2e-5
+    assert maxrel(ovae.posterior_sample(mom, None), g["z_mode"]) < 2e-5
+    rec = ovae.decode(sd, cfg, T(g["z"]))
+    assert maxrel(rec, g["rec"]) < 5e-5
+
+
+def _ms_for(tag):
+    if tag == "256":
+        return oddim.ModelSchedule(parameterization="eps")
+    base = 0.7 if tag == "512" else 0.3
+    return oddim.ModelSchedule(rescale_betas_zero_snr=True, parameterization="v", use_dynamic_rescale=True,
+                               base_scale=base)
+
+
+def test_schedules_bit_exact():
+    g = load("schedules")
+    for tag in ("256", "512", "1024"):
+        ms = _ms_for(tag)
+        for k in ("betas", "alphas_cumprod", "alphas_cumprod_prev", "sqrt_alphas_cumprod",
+                  "sqrt_one_minus_alphas_cumprod"):
+            assert np.array_equal(getattr(ms, k).numpy(), g[f"{tag}/{k}"]), (tag, k)
+        if ms.use_dynamic_rescale:
+            assert np.array_equal(ms.scale_arr.numpy(), g[f"{tag}/scale_arr"])
+            assert ms.scale_arr.numel() == 1400
+        for S in (10, 50):
+            for disc in ("uniform", "uniform_trailing"):
+                for eta in (0, 1):
+                    key = f"{tag}/S{S}/{disc}/eta{eta}"
+                    sc = oddim.DDIMSchedule(ms, S, disc, float(eta))
+                    assert np.array_equal(sc.ddim_timesteps, g[key + "/ddim_timesteps"]), key
+                    for nm in ("a_t", "a_prev", "sigma_t", "sqrt_one_minus_at"):
+                        assert np.array_equal(sc.tables[nm].numpy(), g[f"{key}/{nm}"], equal_nan=True), (key, nm)
+                    if ms.use_dynamic_rescale:
+                        assert np.array_equal(sc.tables["scale_t"].numpy(), g[key + "/scale_t"])
+                        assert np.array_equal(sc.tables["scale_prev"].numpy(), g[key + "/scale_prev"])
+
+
+def test_p_sample_ddim_known_answers():
+    g = load("p_sample_ddim")
+    x, ec, eu, ei, noise = (T(g[k]) for k in ("x", "e_cond", "e_uncond", "e_img", "noise"))
+    n = 0
+    for tag, disc, gr in (("256", "uniform", 0.0), ("512", "uniform_trailing", 0.7), ("1024", "uniform_trailing", 0.7)):
+        ms = _ms_for(tag)
+        for eta in (0, 1):
+            sc = oddim.DDIMSchedule(ms, 10, disc, float(eta))
+            for index in (9, 4, 0):
+                for nm in ("cfg2", "cfg3"):
+                    key = f"{tag}/{disc}/eta{eta}/i{index}/{nm}"
+                    xp, px0 = oddim.p_sample_ddim(sc, x, index, ec, eu, ei if nm == "cfg3" else None, cfg_scale=7.5,
+                                                  cfg_img=2.0, guidance_rescale=gr, noise=noise)
+                    ref_xp, ref_px0 = g[key + "/x_prev"], g[key + "/pred_x0"]
+                    if not np.isfinite(ref_xp).all():
+                        # the reference's sqrt(1 - a_prev - sigma^2) hazard; the build clamps at 0
+                        assert torch.isfinite(xp).all()
+                        continue
+                    assert maxrel(px0, ref_px0) < 1e-5, key
+                    assert maxrel(xp, ref_xp) < 1e-5, key
+                    n += 1
+    assert n >= 30
+
+
+@pytest.mark.parametrize("tag,disc,eta,gr", [("256", "uniform", 0.0, 0.0), ("512", "uniform_trailing", 1.0, 0.7)])
+def test_trajectory_matches_reference(tag, disc, eta, gr):
+    g = load(f"trajectory_{tag}")
+    params = yaml.safe_load(str(g["yaml_unet"]))
+    cfg = ounet.UNetCfg.from_params(params)
+    sd = fill_state_dict(ounet.unet_param_shapes(cfg), seed=11)
+    ms = _ms_for(tag)
+    sc = oddim.DDIMSchedule(ms, 10, disc, eta)
+    cc = T(g["c_concat"])
+
+    def apply_model(x, t, cond, fs=None):          # DiffusionWrapper 'hybrid' ddpm3d.py:1254-1258
+        return ounet.unet_forward(sd, cfg, torch.cat([x, cc], dim=1), t, cond, fs)
+
+    out = oddim.ddim_sample(apply_model, sc, T(g["x_T"]), T(g["ctx"]), T(g["uc_ctx"]), cfg_scale=7.5,
+                            guidance_rescale=gr, noises=list(T(g["noises"])) if eta > 0 else None, fs=T(g["fs"]))
+    assert maxrel(out, g["samples"]) < 2e-4
+
+
+def test_first_stage_matches_reference():
+    g = load("first_stage")
+    cfg = ovae.AECfg(ch=32)
+    sd = fill_state_dict(ovae.ae_param_shapes(cfg), seed=13)
+    sf = float(g["scale_factor"])
+    vid = T(g["video"])
+    noise = T(g["noise"])                      # one draw per frame, frame order (perframe_ae loop)
+    z = ovae.encode_first_stage(sd, cfg, vid, sf, noise)
+    assert maxrel(z, g["z"]) < 2e-5
+    rec = ovae.decode_first_stage(sd, cfg, T(g["z"]), sf)
+    assert maxrel(rec, g["rec"]) < 5e-5
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(G, "unet_fullwidth_8x8.npz")), reason="fixture not generated")
+def test_unet_fullwidth_key_inventory():
+    """1516 tensors / 1 438 854 980 parameters with the reference's exact names and shapes (b)."""
+    g = load("unet_fullwidth_8x8")
+    cfg = ounet.UNetCfg(default_fs=10)
+    shapes = ounet.unet_param_shapes(cfg)
+    mine = sorted(f"{k}:{'x'.join(map(str, s))}" for k, s in shapes.items())
+    assert mine == [str(s) for s in g["key_digest"]]
+    assert int(g["n_tensors"]) == len(shapes) == 1516
+    assert int(g["n_params"]) == sum(int(np.prod(s)) for s in shapes.values()) == 1438854980
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(G, "unet_fullwidth_8x8.npz")), reason="fixture not generated")
+def test_unet_fullwidth_matches_reference():
+    """The released architecture (1.44 B parameters, recipe weights) at an 8x8 latent, T=16."""
+    g = load("unet_fullwidth_8x8")
+    cfg = ounet.UNetCfg(default_fs=10)
+    sd = fill_state_dict(ounet.unet_param_shapes(cfg), seed=12)
+    y = ounet.unet_forward(sd, cfg, T(g["x"]), T(g["timesteps"]), T(g["context"]), T(g["fs"]))
+    assert maxrel(y, g["y"]) < 5e-5
