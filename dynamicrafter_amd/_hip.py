@@ -37,6 +37,7 @@ class DcDdimParams(C.Structure):
         ("index", C.c_int), ("v_param", C.c_int),
         ("cfg_scale", C.c_float), ("cfg_img", C.c_float), ("guidance_rescale", C.c_float),
         ("temperature", C.c_float),
+        ("e_nchw", C.c_int), ("noise_step_stride", C.c_int64),
     ]
 
 
@@ -57,6 +58,7 @@ SIGNATURES = {
     "dc_copy2d": (_I, [_P, _I, _P, _I, _I, _I, _P]),
     "dc_build_context": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
     "dc_softmax_rows": (_I, [_P, _I, _P, _I, _I, _I, _P]),
+    "dc_transpose": (_I, [_P, _I, _P, _I, _I, _I, _P]),
     "dc_add_rows": (_I, [_P, _I, _P, _I, _P, _I, _I, _I, _P]),
     "dc_vae_sample": (_I, [_P, _I, _P, _P, _I, _I, _I, _F, _P]),
     "dc_ddim_step": (_I, [C.POINTER(DcDdimParams), _P, _P, _P, _I, _P, _P, _P, _P, _I, _I, _I, _P, _P]),

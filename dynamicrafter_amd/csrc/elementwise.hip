@@ -221,6 +221,11 @@ __global__ void vae_sample_kernel(const bf16_t* __restrict__ mom, int ld, const 
 // order, then applies guidance rescale, v->eps/x0, dynamic rescale and the DDIM step elementwise.
 constexpr int DDIM_BLOCKS = 256;   // partial blocks per sample
 
+__device__ __forceinline__ size_t ddim_eoff(const DcDdimParams& p, int b, int c, int pos, int C, int THW, int ld_e) {
+    // channels-last rows [b][pos][ld_e] (UNet row output) or the reference's [b][c][pos] layout
+    return p.e_nchw ? ((size_t)b * C + c) * THW + pos : ((size_t)b * THW + pos) * ld_e + c;
+}
+
 __device__ __forceinline__ float ddim_cfg(const DcDdimParams& p, const float* ec, const float* eu, const float* ei,
                                           size_t off) {
     const float c = ec[off];
@@ -233,6 +238,17 @@ __device__ __forceinline__ float ddim_cfg(const DcDdimParams& p, const float* ec
     return u + p.cfg_scale * (c - u);
 }
 
+// (1 - a_prev - sigma^2).sqrt() with separately rounded multiply and subtractions, as torch evaluates it
+// (ddim.py:271). hipcc contracts a*b-c into an FMA by default, which turns the exact 0 (or one-ulp) radicand of
+// the first zero-terminal-SNR step into ~2e-8 and shifts x_prev by ~1e-4: contraction is switched off here.
+__device__ __forceinline__ float ddim_dir_coef(float a_prev, float sigma) {
+#pragma clang fp contract(off)
+    const float s2 = sigma * sigma;
+    const float one_minus = 1.f - a_prev;
+    const float r = one_minus - s2;
+    return sqrtf(fmaxf(r, 0.f));
+}
+
 __global__ __launch_bounds__(256) void ddim_partial_kernel(const DcDdimParams p, const float* __restrict__ ec,
                                                            const float* __restrict__ eu, const float* __restrict__ ei,
                                                            int ld_e, int C, int THW, float* __restrict__ ws) {
@@ -242,7 +258,7 @@ __global__ __launch_bounds__(256) void ddim_partial_kernel(const DcDdimParams p,
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)DDIM_BLOCKS * 256) {
         const int pos = (int)(i / C), c = (int)(i - (int64_t)pos * C);
-        const size_t off = ((size_t)b * THW + pos) * ld_e + c;
+        const size_t off = ddim_eoff(p, b, c, pos, C, THW, ld_e);
         const float cfg = ddim_cfg(p, ec, eu, ei, off);
         const float e = ec[off];
         s0 += cfg; s1 += cfg * cfg; s2 += e; s3 += e * e;
@@ -283,6 +299,7 @@ __global__ __launch_bounds__(256) void ddim_apply_kernel(const DcDdimParams p, c
         factor = p.guidance_rescale * ratio + (1.f - p.guidance_rescale);
     }
     const int idx = p.step_index ? p.step_index[0] : p.index;
+    if (noise && p.step_index) noise += (size_t)idx * p.noise_step_stride;
     const float a_t = p.a_t[idx], a_prev = p.a_prev[idx], sigma = p.sigma_t[idx], s1m = p.sqrt_one_minus_at[idx];
     const float sq_acp = p.v_param ? p.sqrt_acp_t[idx] : 0.f;
     const float sq_1macp = p.v_param ? p.sqrt_1macp_t[idx] : 0.f;
@@ -292,10 +309,10 @@ __global__ __launch_bounds__(256) void ddim_apply_kernel(const DcDdimParams p, c
     // (1 - a_prev - sigma^2).sqrt() in fp32, same association as ddim.py:271. With zero-terminal-SNR +
     // uniform_trailing + eta=1 the radicand is +5.96e-8 at the first step; clamp at 0 so a one-ulp
     // difference can never produce NaN (the reference's get_fixed_ddim_sampler exists for that hazard).
-    const float dir_coef = sqrtf(fmaxf(1.f - a_prev - sigma * sigma, 0.f));
+    const float dir_coef = ddim_dir_coef(a_prev, sigma);
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
         const int c = (int)(i / THW), pos = (int)(i - (int64_t)c * THW);     // NCTHW order for x / outputs
-        const size_t eoff = ((size_t)b * THW + pos) * ld_e + c;
+        const size_t eoff = ddim_eoff(p, b, c, pos, C, THW, ld_e);
         const size_t xoff = (size_t)b * n + i;
         const float mo = ddim_cfg(p, ec, eu, ei, eoff) * factor;
         const float xv = x[xoff];
@@ -311,6 +328,24 @@ __global__ __launch_bounds__(256) void ddim_apply_kernel(const DcDdimParams p, c
         const float nz = noise ? sigma * noise[xoff] * p.temperature : 0.f;
         x_prev[xoff] = sqrt_aprev * px0 + dir_coef * e_t + nz;   // ddim.py:271-277
         pred_x0[xoff] = px0;
+    }
+}
+
+
+// dst[c][r] = src[r][c] for bf16 rows; 64x64 tiles through LDS (pad column against bank conflicts)
+__global__ __launch_bounds__(256) void transpose_kernel(const bf16_t* __restrict__ src, int lds_, bf16_t* __restrict__ dst,
+                                                        int ldd, int rows, int cols) {
+    __shared__ bf16_t tile[64][66];
+    const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int i = ty; i < 64; i += 4) {
+        const int r = r0 + i, c = c0 + tx;
+        tile[i][tx] = (r < rows && c < cols) ? src[(size_t)r * lds_ + c] : (bf16_t)0;
+    }
+    __syncthreads();
+    for (int i = ty; i < 64; i += 4) {
+        const int c = c0 + i, r = r0 + tx;
+        if (c < cols && r < rows) dst[(size_t)c * ldd + r] = tile[tx][i];
     }
 }
 
@@ -451,6 +486,15 @@ extern "C" int dc_ddim_step(const DcDdimParams* pp, const float* e_cond, const f
 extern "C" int dc_advance_counter(int32_t* counter, void* stream_) {
     if (!counter) return DC_ERR_ARG;
     hipLaunchKernelGGL(advance_counter_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream_, counter);
+    DC_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int dc_transpose(const uint16_t* src, int lds_, uint16_t* dst, int ldd, int rows, int cols, void* stream_) {
+    if (!src || !dst) return DC_ERR_ARG;
+    if (rows < 1 || cols < 1) return DC_ERR_SHAPE;
+    hipLaunchKernelGGL(transpose_kernel, dim3((cols + 63) / 64, (rows + 63) / 64), dim3(256), 0, (hipStream_t)stream_,
+                       src, lds_, dst, ldd, rows, cols);
     DC_CHECK_LAUNCH();
     return 0;
 }

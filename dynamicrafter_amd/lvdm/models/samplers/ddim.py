@@ -1,0 +1,264 @@
+"""DDIMSampler — the reference's sampler API (lvdm/models/samplers/ddim.py:10-317) over the fused HIP step.
+
+`DDIMSampler(model).sample(S, batch_size, shape, conditioning, ..., x_T, unconditional_guidance_scale,
+unconditional_conditioning, eta, fs, timestep_spacing, guidance_rescale, **kwargs) -> (samples, intermediates)`
+behaves as the reference's, including the 3-branch guidance of ddim_multiplecond.py (pass `cfg_img` and
+`unconditional_conditioning_img_nonetext`). Differences by design:
+  * per step, the cond / uncond (/ image-only) UNet evaluations run as ONE batched forward
+    (`model.apply_model_rows`) and CFG combine + guidance-rescale + v->eps/x0 + dynamic rescale + the DDIM update
+    are one fused kernel (dc_ddim_step) instead of ~25 elementwise launches and 6 host->device scalars;
+  * per-step scalars live in device tables indexed by a device-side step counter, so one captured hipGraph of
+    a step is replayed S times (`use_graph=True`);
+  * `noises=` (tensor [S, *x.shape]) injects the per-step Gaussian noise (parity tests); otherwise it is drawn
+    with torch.randn on the device as the reference does (common.py:31-34).
+  * sqrt(1 - a_prev - sigma^2) is clamped at 0 (the reference can produce NaN there: SURVEY §8 a2).
+"""
+import numpy as np
+import torch
+
+from .... import ops
+from ..utils_diffusion import make_ddim_sampling_parameters, make_ddim_timesteps
+
+
+class DDIMSampler(object):
+    def __init__(self, model, schedule="linear", **kwargs):
+        super().__init__()
+        self.model = model
+        self.ddpm_num_timesteps = model.num_timesteps
+        self.schedule = schedule
+        self.counter = 0
+        self._graph = None
+        self._graph_key = None
+
+    def register_buffer(self, name, attr):
+        setattr(self, name, attr)
+
+    # ------------------------------------------------------------------ schedule (host, once per call)
+    def make_schedule(self, ddim_num_steps, ddim_discretize="uniform", ddim_eta=0., verbose=True):
+        m = self.model
+        self.ddim_timesteps = make_ddim_timesteps(ddim_discr_method=ddim_discretize, num_ddim_timesteps=ddim_num_steps,
+                                                  num_ddpm_timesteps=self.ddpm_num_timesteps, verbose=verbose)
+        acp = m.alphas_cumprod.detach().float().cpu()
+        assert acp.shape[0] == self.ddpm_num_timesteps, "alphas have to be defined for each timestep"
+        dev = m.device
+        if getattr(m, "use_dynamic_rescale", False):
+            sa = m.scale_arr.detach().cpu()[self.ddim_timesteps]
+            self.ddim_scale_arr = sa
+            self.ddim_scale_arr_prev = torch.cat([sa[0:1], sa[:-1]])
+        sig, a, a_prev = make_ddim_sampling_parameters(alphacums=acp, ddim_timesteps=self.ddim_timesteps, eta=ddim_eta,
+                                                       verbose=verbose)
+        self.ddim_sigmas, self.ddim_alphas, self.ddim_alphas_prev = sig, a, a_prev
+        self.ddim_sqrt_one_minus_alphas = np.sqrt(1. - a.numpy())
+        for k in ("betas", "alphas_cumprod", "alphas_cumprod_prev", "sqrt_alphas_cumprod",
+                  "sqrt_one_minus_alphas_cumprod"):
+            setattr(self, k, getattr(m, k).detach().float().to(dev))
+        # fp32 tables in EXECUTION order (step i uses DDIM index S-1-i): what torch.full(size, v) would hold
+        S = self.ddim_timesteps.shape[0]
+        order = np.arange(S)[::-1].copy()
+        f32 = lambda v: torch.as_tensor(np.asarray(v, dtype=np.float64)).float()[order].contiguous().to(dev)
+        ts = torch.as_tensor(self.ddim_timesteps.copy(), dtype=torch.long)
+        t = {"a_t": a.float()[order].contiguous().to(dev), "a_prev": f32(a_prev), "sigma_t": f32(sig.numpy()),
+             "sqrt_one_minus_at": torch.as_tensor(self.ddim_sqrt_one_minus_alphas)[order].contiguous().to(dev),
+             "sqrt_acp_t": m.sqrt_alphas_cumprod.detach().float().cpu()[ts][order].contiguous().to(dev),
+             "sqrt_1macp_t": m.sqrt_one_minus_alphas_cumprod.detach().float().cpu()[ts][order].contiguous().to(dev)}
+        if getattr(m, "use_dynamic_rescale", False):
+            t["scale_ratio"] = (self.ddim_scale_arr_prev / self.ddim_scale_arr)[order].contiguous().to(dev)
+        self._tables = t
+        self._exec_timesteps = np.flip(self.ddim_timesteps).copy()
+
+    # ------------------------------------------------------------------ public API
+    @torch.no_grad()
+    def sample(self, S, batch_size, shape, conditioning=None, callback=None, normals_sequence=None, img_callback=None,
+               quantize_x0=False, eta=0., mask=None, x0=None, temperature=1., noise_dropout=0., score_corrector=None,
+               corrector_kwargs=None, verbose=True, schedule_verbose=False, x_T=None, log_every_t=100,
+               unconditional_guidance_scale=1., unconditional_conditioning=None, precision=None, fs=None,
+               timestep_spacing="uniform", guidance_rescale=0.0, **kwargs):
+        if conditioning is not None and isinstance(conditioning, dict):
+            first = conditioning[list(conditioning.keys())[0]]
+            cbs = (first[0] if isinstance(first, (list, tuple)) else first).shape[0]
+            if cbs != batch_size:
+                print(f"Warning: Got {cbs} conditionings but batch-size is {batch_size}")
+        self.make_schedule(ddim_num_steps=S, ddim_discretize=timestep_spacing, ddim_eta=eta, verbose=schedule_verbose)
+        size = (batch_size,) + tuple(shape)
+        return self.ddim_sampling(conditioning, size, callback=callback, img_callback=img_callback, mask=mask, x0=x0,
+                                  noise_dropout=noise_dropout, temperature=temperature,
+                                  score_corrector=score_corrector, x_T=x_T, log_every_t=log_every_t,
+                                  unconditional_guidance_scale=unconditional_guidance_scale,
+                                  unconditional_conditioning=unconditional_conditioning, verbose=verbose,
+                                  precision=precision, fs=fs, guidance_rescale=guidance_rescale,
+                                  quantize_denoised=quantize_x0, **kwargs)
+
+    def _branches(self, cond, uc, scale, kwargs):
+        br = [cond]
+        if uc is not None and scale != 1.:
+            br.append(uc)
+            uc2 = kwargs.get("unconditional_conditioning_img_nonetext")
+            if uc2 is not None:
+                br.append(uc2)
+        return br
+
+    @torch.no_grad()
+    def ddim_sampling(self, cond, shape, x_T=None, ddim_use_original_steps=False, callback=None, timesteps=None,
+                      quantize_denoised=False, mask=None, x0=None, img_callback=None, log_every_t=100, temperature=1.,
+                      noise_dropout=0., score_corrector=None, corrector_kwargs=None, unconditional_guidance_scale=1.,
+                      unconditional_conditioning=None, verbose=True, precision=None, fs=None, guidance_rescale=0.0,
+                      noises=None, use_graph=False, **kwargs):
+        if ddim_use_original_steps or timesteps is not None or quantize_denoised or score_corrector is not None \
+                or noise_dropout > 0.:
+            raise NotImplementedError("only the options DynamiCrafter inference uses are implemented "
+                                      "(no original-steps / partial / quantised / corrected sampling)")
+        m = self.model
+        dev = m.device
+        if dev.type != "cuda":
+            raise RuntimeError("DDIMSampler runs on the HIP path only: put the model on the GPU")
+        b = shape[0]
+        img = (torch.randn(shape, device=dev) if x_T is None else x_T.to(dev)).to(torch.float32).contiguous().clone()
+        S = self._exec_timesteps.shape[0]
+        clean_cond = kwargs.pop("clean_cond", False)
+        cfg_img = kwargs.get("cfg_img")
+        branches = self._branches(cond, unconditional_conditioning, unconditional_guidance_scale, kwargs)
+        nb = len(branches)
+        if cfg_img is None:
+            cfg_img = unconditional_guidance_scale
+        eta_on = bool((self._tables["sigma_t"] != 0).any().item())
+        if noises is None and eta_on:
+            # drawn up front so a captured graph can index them by the device step counter (same stream of
+            # torch.randn draws as the reference's per-step noise_like calls)
+            noises = torch.stack([torch.randn(shape, device=dev) for _ in range(S)])
+        if noises is not None:
+            noises = noises.to(device=dev, dtype=torch.float32).contiguous()
+        v_param = m.parameterization == "v"
+        C_, THW = shape[1], int(np.prod(shape[2:]))
+        pred_x0 = torch.empty_like(img)
+        ws = torch.empty(16 * b * 256, dtype=torch.float32, device=dev)
+        counter = torch.zeros(1, dtype=torch.int32, device=dev)
+        t_host = torch.as_tensor(self._exec_timesteps.copy(), dtype=torch.int64)
+        t_table = t_host[:, None].repeat(1, nb * b).contiguous().to(dev)          # [S, nb*B]
+        fast = hasattr(m, "apply_model_rows") and all(isinstance(c, dict) for c in branches)
+        prep = m.prepare_branches(shape, branches, fs=fs) if fast else None
+        intermediates = {"x_inter": [img.clone()], "pred_x0": [img.clone()]}
+
+        def one_step():
+            if fast:
+                e = m.apply_model_rows(img, prep, t_table, t_index=counter)
+                M = b * THW
+                e_c, e_u = e[:M], (e[M:2 * M] if nb > 1 else None)
+                e_i = e[2 * M:3 * M] if nb > 2 else None
+                ops.ddim_step(self._tables, e_c, e_u, e_i, img, noises, img, pred_x0, ws, B=b, Cc=C_, THW=THW,
+                              step_index=counter, v_param=v_param, cfg_scale=unconditional_guidance_scale,
+                              cfg_img=cfg_img, guidance_rescale=guidance_rescale, temperature=temperature,
+                              noise_step_stride=img.numel())
+            else:
+                raise RuntimeError("generic model path is handled outside one_step")
+            ops.advance_counter(counter)
+
+        if fast and mask is None:
+            if use_graph:
+                one_step()                                   # eager warm-up: allocates every scratch buffer
+                torch.cuda.synchronize()
+                counter.fill_(1)
+                g = ops.DeviceGraph().capture(one_step)
+                counter.fill_(1)
+                torch.cuda.synchronize()
+                for i in range(1, S):
+                    g.launch()
+                g.sync()
+                self._graph = g
+            else:
+                for i in range(S):
+                    one_step()
+                    index = S - i - 1
+                    if callback: callback(i)
+                    if img_callback: img_callback(pred_x0, i)
+                    if index % log_every_t == 0 or index == S - 1:
+                        intermediates["x_inter"].append(img.clone())
+                        intermediates["pred_x0"].append(pred_x0.clone())
+            return img, intermediates
+
+        # generic path: any model exposing apply_model(x, t, c, **kw) -> [B, C, ...] (also mask / x0 blending)
+        for i, step in enumerate(self._exec_timesteps):
+            index = S - i - 1
+            ts = torch.full((b,), int(step), device=dev, dtype=torch.long)
+            if mask is not None:
+                assert x0 is not None
+                img_orig = x0 if clean_cond else m.q_sample(x0, ts)
+                img = img_orig * mask + (1. - mask) * img
+            img, pred_x0 = self.p_sample_ddim(img, cond, ts, index=index, temperature=temperature,
+                                              unconditional_guidance_scale=unconditional_guidance_scale,
+                                              unconditional_conditioning=unconditional_conditioning, fs=fs,
+                                              guidance_rescale=guidance_rescale,
+                                              noise=None if noises is None else noises[i], **kwargs)
+            if callback: callback(i)
+            if img_callback: img_callback(pred_x0, i)
+            if index % log_every_t == 0 or index == S - 1:
+                intermediates["x_inter"].append(img)
+                intermediates["pred_x0"].append(pred_x0)
+        return img, intermediates
+
+    @torch.no_grad()
+    def p_sample_ddim(self, x, c, t, index, repeat_noise=False, use_original_steps=False, quantize_denoised=False,
+                      temperature=1., noise_dropout=0., score_corrector=None, corrector_kwargs=None,
+                      unconditional_guidance_scale=1., unconditional_conditioning=None, uc_type=None,
+                      conditional_guidance_scale_temporal=None, mask=None, x0=None, guidance_rescale=0.0, noise=None,
+                      cfg_img=None, **kwargs):
+        """One DDIM update from separate apply_model calls (reference :205-279 / multiplecond :211-285)."""
+        if use_original_steps or quantize_denoised or score_corrector is not None or noise_dropout > 0.:
+            raise NotImplementedError
+        m = self.model
+        dev = x.device
+        x = x.to(torch.float32).contiguous()
+        uc2 = kwargs.pop("unconditional_conditioning_img_nonetext", None)
+        kwargs.pop("clean_cond", None)
+        mk = {k: v for k, v in kwargs.items() if k == "fs"}
+        e_c = m.apply_model(x, t, c, **mk).to(torch.float32).contiguous()
+        e_u = e_i = None
+        if unconditional_conditioning is not None and unconditional_guidance_scale != 1.:
+            e_u = m.apply_model(x, t, unconditional_conditioning, **mk).to(torch.float32).contiguous()
+            if uc2 is not None:
+                e_i = m.apply_model(x, t, uc2, **mk).to(torch.float32).contiguous()
+        if cfg_img is None:
+            cfg_img = unconditional_guidance_scale
+        S = self._exec_timesteps.shape[0]
+        if noise is None:
+            noise = torch.randn(x.shape, device=dev)        # drawn even when sigma == 0, as the reference does
+            if repeat_noise:
+                noise = noise[:1].expand_as(x)
+        noise = noise.to(torch.float32).contiguous()
+        b = x.shape[0]
+        x_prev, pred_x0 = torch.empty_like(x), torch.empty_like(x)
+        ws = torch.empty(16 * b * 256, dtype=torch.float32, device=dev)
+        ops.ddim_step(self._tables, e_c, e_u, e_i, x, noise, x_prev, pred_x0, ws, B=b, Cc=x.shape[1],
+                      THW=int(np.prod(x.shape[2:])), index=S - 1 - index, v_param=m.parameterization == "v",
+                      cfg_scale=unconditional_guidance_scale, cfg_img=cfg_img, guidance_rescale=guidance_rescale,
+                      temperature=temperature, e_nchw=True)
+        return x_prev, pred_x0
+
+    @torch.no_grad()
+    def stochastic_encode(self, x0, t, use_original_steps=False, noise=None):
+        """ddim.py:303-317 (tiny elementwise helper, torch)."""
+        if use_original_steps:
+            sa, s1 = self.sqrt_alphas_cumprod, self.sqrt_one_minus_alphas_cumprod
+        else:
+            sa = torch.sqrt(self.ddim_alphas).to(x0.device)
+            s1 = torch.as_tensor(self.ddim_sqrt_one_minus_alphas).to(x0.device)
+        noise = torch.randn_like(x0) if noise is None else noise
+        shp = (t.shape[0],) + (1,) * (x0.dim() - 1)
+        return sa.to(x0.device)[t].reshape(shp) * x0 + s1[t].reshape(shp) * noise
+
+    @torch.no_grad()
+    def decode(self, x_latent, cond, t_start, unconditional_guidance_scale=1.0, unconditional_conditioning=None,
+               use_original_steps=False, callback=None):
+        """ddim.py:281-301: run the last t_start DDIM steps from x_latent."""
+        if use_original_steps:
+            raise NotImplementedError
+        S = self.ddim_timesteps.shape[0]
+        steps = np.flip(self.ddim_timesteps[:t_start])
+        x_dec = x_latent
+        for i, step in enumerate(steps):
+            index = steps.shape[0] - i - 1
+            ts = torch.full((x_latent.shape[0],), int(step), device=x_latent.device, dtype=torch.long)
+            x_dec, _ = self.p_sample_ddim(x_dec, cond, ts, index=index,
+                                          unconditional_guidance_scale=unconditional_guidance_scale,
+                                          unconditional_conditioning=unconditional_conditioning)
+            if callback: callback(i)
+        return x_dec

@@ -166,12 +166,15 @@ def layernorm(x, y, gamma, beta, eps=1e-5):
     return y
 
 
-def flash_attn(q, k, v, o, *, batch, heads, Lq, Lk, scale, accumulate=False, acc_scale=1.0):
-    """q/o rows [batch*Lq, >=heads*64]; k/v rows [batch*Lk, ...] (views into a fused qkv buffer are fine)."""
+def flash_attn(q, k, v, o, *, batch, heads, Lq, Lk, scale, accumulate=False, acc_scale=1.0, q_bstride=None,
+               kv_bstride=None):
+    """q/o rows [batch*Lq, >=heads*64]; k/v rows [batch*Lk, ...] (views into a fused qkv buffer are fine).
+    q_bstride / kv_bstride: rows between consecutive batch items (default Lq / Lk)."""
     for t, n in ((q, "q"), (k, "k"), (v, "v"), (o, "o")):
         _rows(t, n)
     check(_hip.lib().dc_flash_attn_d64(_ptr(q), _ptr(k), _ptr(v), _ptr(o), q.stride(0), k.stride(0), v.stride(0),
-                                       o.stride(0), batch, heads, Lq, Lk, Lq, Lk, scale, 1 if accumulate else 0,
+                                       o.stride(0), batch, heads, Lq, Lk, Lq if q_bstride is None else q_bstride,
+                                       Lk if kv_bstride is None else kv_bstride, scale, 1 if accumulate else 0,
                                        acc_scale, stream_ptr()), "dc_flash_attn_d64")
     return o
 
@@ -223,6 +226,15 @@ def copy2d(src, dst, cols=None):
     return dst
 
 
+def transpose(src, dst, rows=None, cols=None):
+    """dst[c, r] = src[r, c] (bf16)."""
+    rows = src.shape[0] if rows is None else rows
+    cols = src.shape[1] if cols is None else cols
+    check(_hip.lib().dc_transpose(_ptr(src), src.stride(0), _ptr(dst), dst.stride(0), rows, cols, stream_ptr()),
+          "dc_transpose")
+    return dst
+
+
 def add_rows(a, b, y):
     check(_hip.lib().dc_add_rows(_ptr(a), a.stride(0), _ptr(b), b.stride(0), _ptr(y), y.stride(0), a.shape[0],
                                  a.shape[1], stream_ptr()), "dc_add_rows")
@@ -247,7 +259,8 @@ def vae_sample(moments, noise, z, *, N, zc, HW, scale):
 
 
 def ddim_step(tables, e_cond, e_uncond, e_img, x, noise, x_prev, pred_x0, workspace, *, B, Cc, THW, index=0,
-              step_index=None, v_param=False, cfg_scale=1.0, cfg_img=1.0, guidance_rescale=0.0, temperature=1.0):
+              step_index=None, v_param=False, cfg_scale=1.0, cfg_img=1.0, guidance_rescale=0.0, temperature=1.0,
+              e_nchw=False, ld_e=None, noise_step_stride=0):
     """tables: dict of fp32 device vectors (a_t, a_prev, sigma_t, sqrt_one_minus_at[, sqrt_acp_t, sqrt_1macp_t,
     scale_ratio]) indexed by the DDIM index."""
     p = DcDdimParams()
@@ -257,7 +270,10 @@ def ddim_step(tables, e_cond, e_uncond, e_img, x, noise, x_prev, pred_x0, worksp
     p.step_index = 0 if step_index is None else step_index.data_ptr()
     p.index, p.v_param = index, 1 if v_param else 0
     p.cfg_scale, p.cfg_img, p.guidance_rescale, p.temperature = cfg_scale, cfg_img, guidance_rescale, temperature
-    check(_hip.lib().dc_ddim_step(C.byref(p), _ptr(e_cond), _ptr(e_uncond), _ptr(e_img), e_cond.stride(0), _ptr(x),
+    p.e_nchw, p.noise_step_stride = 1 if e_nchw else 0, noise_step_stride
+    if ld_e is None:
+        ld_e = 0 if e_nchw else e_cond.stride(0)
+    check(_hip.lib().dc_ddim_step(C.byref(p), _ptr(e_cond), _ptr(e_uncond), _ptr(e_img), ld_e, _ptr(x),
                                   _ptr(noise), _ptr(x_prev), _ptr(pred_x0), B, Cc, THW, _ptr(workspace),
                                   stream_ptr()), "dc_ddim_step")
     return x_prev, pred_x0

@@ -123,6 +123,9 @@ int dc_build_context(const float* ctx, uint16_t* out, int B, int T, int n_text, 
 /* Row softmax fp32 -> bf16 (AutoencoderKL mid attention, ae_modules.py:68). */
 int dc_softmax_rows(const float* x, int ldx, uint16_t* y, int ldy, int rows, int cols, void* stream);
 
+/* dst[c][r] = src[r][c] on bf16 rows (V^T operand of the AutoencoderKL mid attention, ae_modules.py:71-74). */
+int dc_transpose(const uint16_t* src, int lds, uint16_t* dst, int ldd, int rows, int cols, void* stream);
+
 /* y = a + b elementwise on bf16 rows (AE residual adds where no GEMM epilogue is available). */
 int dc_add_rows(const uint16_t* a, int lda, const uint16_t* b, int ldb, uint16_t* y, int ldy, int rows, int cols,
                 void* stream);
@@ -149,6 +152,8 @@ typedef struct DcDdimParams {
     float cfg_img;               /* 3-branch CFG (ddim_multiplecond.py:234); used when e_img != NULL */
     float guidance_rescale;      /* 0 -> off */
     float temperature;
+    int e_nchw;                  /* 0: e_* are channels-last rows [B*T*HW, ld_e]; 1: e_* are [B, C, T*HW] like x */
+    int64_t noise_step_stride;   /* with step_index: noise for this step starts at noise + step_index[0]*stride */
 } DcDdimParams;
 
 /* One DDIM update for B clips. e_* are the UNet outputs as channels-last fp32 rows [B*T*HW, ld_e] (first C

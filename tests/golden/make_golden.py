@@ -89,7 +89,7 @@ TINY_UNET = dict(in_channels=8, out_channels=4, model_channels=64, attention_res
                  temporal_selfatt_only=True, use_relative_position=False, use_causal_attention=False,
                  temporal_length=4, addition_attention=True, image_cross_attention=True, default_fs=10,
                  fs_condition=True)
-TINY_AE = dict(double_z=True, z_channels=4, resolution=256, in_channels=3, out_ch=3, ch=32, ch_mult=[1, 2, 4, 4],
+TINY_AE = dict(double_z=True, z_channels=4, resolution=256, in_channels=3, out_ch=3, ch=64, ch_mult=[1, 2, 4, 4],
                num_res_blocks=2, attn_resolutions=[], dropout=0.0)
 
 

@@ -1,0 +1,235 @@
+"""Model-level parity on the GPU: the HIP-backed lvdm classes against (a) golden vectors captured from the
+reference (tests/golden) and (b) the CPU oracle on the same seeded inputs.
+
+Stated tolerances (bf16 storage, fp32 accumulate; oracle/reference are fp32):
+  whole UNet forward      rel-L2 <= 3e-2 and cosine >= 0.999
+  AutoencoderKL enc/dec   rel-L2 <= 3e-2
+  10-step DDIM trajectory rel-L2 <= 1e-1
+  fused DDIM step (fp32)  max-rel <= 1e-5
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+import yaml
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def load(name):
+    return np.load(os.path.join(G, name + ".npz"), allow_pickle=False)
+
+
+def T(a, dev=DEV):
+    return torch.from_numpy(np.asarray(a)).to(dev)
+
+
+def rel_l2(a, b):
+    a = torch.as_tensor(a).float().cpu(); b = torch.as_tensor(b).float().cpu()
+    return ((a - b).norm() / b.norm().clamp_min(1e-12)).item()
+
+
+def cosine(a, b):
+    a = torch.as_tensor(a).float().cpu().flatten(); b = torch.as_tensor(b).float().cpu().flatten()
+    return (a @ b / (a.norm() * b.norm())).item()
+
+
+def maxrel(a, b):
+    a = torch.as_tensor(a).double().cpu(); b = torch.as_tensor(b).double().cpu()
+    return ((a - b).abs().max() / b.abs().max().clamp_min(1e-30)).item()
+
+
+def recipe_load(module, seed):
+    from oracle.weights import fill_state_dict
+    sd = module.state_dict()
+    module.load_state_dict(fill_state_dict({k: tuple(v.shape) for k, v in sd.items()}, seed), strict=True)
+    return module
+
+
+@pytest.mark.parametrize("tag", ["v1024", "v256"])
+def test_unet_tiny_vs_reference(tag):
+    from dynamicrafter_amd.lvdm.modules.networks.openaimodel3d import UNetModel
+    g = load(f"unet_tiny_{tag}")
+    params = yaml.safe_load(str(g["yaml_params"]))
+    net = UNetModel(**params)
+    assert sorted(net.state_dict().keys()) == [str(s) for s in g["param_names"]]
+    recipe_load(net, 11).to(DEV)
+    y = net(T(g["x"]), T(g["timesteps"]), context=T(g["context"]), fs=T(g["fs"]))
+    assert y.shape == g["y"].shape and y.dtype == torch.float32
+    assert rel_l2(y, g["y"]) < 3e-2 and cosine(y, g["y"]) > 0.999
+    y2 = net(T(g["x"]), T(g["timesteps"]), context=T(g["context"]))
+    assert rel_l2(y2, g["y_default_fs"]) < 3e-2
+    # determinism: identical launches give identical bits
+    y3 = net(T(g["x"]), T(g["timesteps"]), context=T(g["context"]))
+    assert torch.equal(y2, y3)
+
+
+def test_unet_fullwidth_vs_reference():
+    """Released architecture (1.44 B params) at an 8x8 latent, 16 frames; weights from the seeded recipe."""
+    from dynamicrafter_amd.lvdm.modules.networks.openaimodel3d import UNetModel
+    g = load("unet_fullwidth_8x8")
+    cfg = yaml.safe_load(open(os.path.join(os.path.dirname(G), "..", "dynamicrafter_amd", "configs",
+                                           "inference_1024_v1.0.yaml")))
+    params = cfg["model"]["params"]["unet_config"]["params"]
+    net = UNetModel(**params)
+    digest = sorted(f"{k}:{'x'.join(map(str, v.shape))}" for k, v in net.state_dict().items())
+    assert digest == [str(s) for s in g["key_digest"]]
+    recipe_load(net, 12).to(DEV)
+    y = net(T(g["x"]), T(g["timesteps"]), context=T(g["context"]), fs=T(g["fs"]))
+    assert rel_l2(y, g["y"]) < 3e-2 and cosine(y, g["y"]) > 0.999
+
+
+@pytest.mark.parametrize("tag", ["tiny", "full"])
+def test_autoencoder_vs_reference(tag):
+    from dynamicrafter_amd.lvdm.models.autoencoder import AutoencoderKL
+    g = load(f"ae_{tag}")
+    dd = yaml.safe_load(str(g["yaml_params"]))
+    ae = AutoencoderKL(ddconfig=dd, lossconfig={"target": "torch.nn.Identity"}, embed_dim=4)
+    assert sorted(ae.state_dict().keys()) == [str(s) for s in g["param_names"]]
+    recipe_load(ae, 13).to(DEV)
+    post = ae.encode(T(g["img"]))
+    assert rel_l2(post.parameters, g["moments"]) < 3e-2
+    z = post.sample(noise=T(g["noise"]))
+    assert rel_l2(z, g["z"]) < 3e-2
+    assert rel_l2(post.mode(), g["z_mode"]) < 3e-2
+    rec = ae.decode(T(g["z"]))
+    assert rec.shape == g["rec"].shape
+    assert rel_l2(rec, g["rec"]) < 3e-2
+
+
+def _tiny_lvd(config_name, unet_extra=None, seed_unet=11, seed_ae=13):
+    """LatentVisualDiffusion from this package's YAML with the golden generator's tiny nets."""
+    from dynamicrafter_amd.utils.utils import instantiate_from_config
+    from tests.golden_cfg import TINY_AE, TINY_UNET
+    root = os.path.join(os.path.dirname(G), "..", "dynamicrafter_amd", "configs")
+    cfg = yaml.safe_load(open(os.path.join(root, config_name)))
+    p = cfg["model"]["params"]
+    p["unet_config"]["params"] = dict(TINY_UNET, default_fs=p["unet_config"]["params"]["default_fs"], **(unet_extra or {}))
+    p["first_stage_config"]["params"]["ddconfig"] = dict(TINY_AE)
+    for k in ("cond_stage_config", "img_cond_stage_config", "image_proj_stage_config"):
+        p[k] = {"target": "torch.nn.Identity"}
+    model = instantiate_from_config(cfg["model"])
+    recipe_load(model.model.diffusion_model, seed_unet)
+    recipe_load(model.first_stage_model, seed_ae)
+    return model.to(DEV)
+
+
+class _Fake:
+    """Schedule carrier whose apply_model returns queued tensors (generic sampler path)."""
+    def __init__(self, real, outs):
+        self.__dict__.update({k: getattr(real, k) for k in ("num_timesteps", "alphas_cumprod", "betas",
+                              "alphas_cumprod_prev", "sqrt_alphas_cumprod", "sqrt_one_minus_alphas_cumprod",
+                              "parameterization", "use_dynamic_rescale")})
+        if real.use_dynamic_rescale:
+            self.scale_arr = real.scale_arr
+        self.device = torch.device(DEV)
+        self._outs = list(outs)
+
+    def apply_model(self, x, t, c, **kw):
+        return self._outs.pop(0)
+
+
+def test_p_sample_ddim_known_answers():
+    """The fused fp32 DDIM kernel against the reference's p_sample_ddim outputs (2- and 3-branch CFG)."""
+    from dynamicrafter_amd.lvdm.models.samplers.ddim import DDIMSampler
+    g = load("p_sample_ddim")
+    x, ec, eu, ei, noise = (T(g[k]) for k in ("x", "e_cond", "e_uncond", "e_img", "noise"))
+    n = 0
+    for cname, disc, gr in (("inference_256_v1.0.yaml", "uniform", 0.0), ("inference_512_v1.0.yaml", "uniform_trailing", 0.7),
+                            ("inference_1024_v1.0.yaml", "uniform_trailing", 0.7)):
+        model = _tiny_lvd(cname)
+        tag = cname.split("_")[1]
+        for eta in (0, 1):
+            for index in (9, 4, 0):
+                for nm in ("cfg2", "cfg3"):
+                    key = f"{tag}/{disc}/eta{eta}/i{index}/{nm}"
+                    s = DDIMSampler(_Fake(model, [ec, eu] + ([ei] if nm == "cfg3" else [])))
+                    s.make_schedule(10, ddim_discretize=disc, ddim_eta=float(eta), verbose=False)
+                    ts = torch.full((x.shape[0],), 1, device=DEV, dtype=torch.long)
+                    extra = dict(cfg_img=2.0, unconditional_conditioning_img_nonetext={"c": 2}) if nm == "cfg3" else {}
+                    xp, px0 = s.p_sample_ddim(x.clone(), {"c": 1}, ts, index=index, unconditional_guidance_scale=7.5,
+                                              unconditional_conditioning={"c": 0}, guidance_rescale=gr, noise=noise,
+                                              **extra)
+                    if not np.isfinite(g[key + "/x_prev"]).all():
+                        assert torch.isfinite(xp).all()
+                        continue
+                    assert maxrel(px0, g[key + "/pred_x0"]) < 1e-5, key
+                    assert maxrel(xp, g[key + "/x_prev"]) < 1e-5, key
+                    n += 1
+    assert n >= 30
+
+
+@pytest.mark.parametrize("tag,disc,eta,gr,extra", [
+    ("256", "uniform", 0.0, 0.0, dict(image_cross_attention_scale_learnable=True)),
+    ("512", "uniform_trailing", 1.0, 0.7, dict())])
+def test_ddim_trajectory_vs_reference(tag, disc, eta, gr, extra):
+    """10 DDIM steps with CFG 7.5 through sampler + hybrid conditioning + UNet, eager and hipGraph-replayed."""
+    from dynamicrafter_amd.lvdm.models.samplers.ddim import DDIMSampler
+    g = load(f"trajectory_{tag}")
+    model = _tiny_lvd(f"inference_{tag}_v1.0.yaml", extra)
+    cond = {"c_crossattn": [T(g["ctx"])], "c_concat": [T(g["c_concat"])]}
+    uc = {"c_crossattn": [T(g["uc_ctx"])], "c_concat": [T(g["c_concat"])]}
+    x_T = T(g["x_T"])
+    outs = []
+    for use_graph in (False, True):
+        s = DDIMSampler(model)
+        samples, inter = s.sample(S=10, batch_size=1, shape=tuple(x_T.shape[1:]), conditioning=cond, verbose=False,
+                                  unconditional_guidance_scale=7.5, unconditional_conditioning=uc, eta=eta, x_T=x_T,
+                                  fs=T(g["fs"]), timestep_spacing=disc, guidance_rescale=gr,
+                                  noises=T(g["noises"]) if eta > 0 else None, use_graph=use_graph)
+        assert torch.isfinite(samples).all()
+        assert rel_l2(samples, g["samples"]) < 1e-1
+        outs.append(samples.clone())
+    assert torch.equal(outs[0], outs[1])          # graph replay == eager launches, bit for bit
+    assert torch.equal(x_T, T(g["x_T"]))          # inputs are not mutated
+
+
+def test_first_stage_vs_reference():
+    g = load("first_stage")
+    model = _tiny_lvd("inference_512_v1.0.yaml")
+    vid = T(g["video"])
+    noise = torch.from_numpy(g["noise"])
+    it = iter([noise[i:i + 1] for i in range(noise.shape[0])])
+    orig = torch.randn
+    torch.randn = lambda *a, **k: next(it)            # posterior.sample() draws CPU torch.randn(shape), as the reference
+    try:
+        z = model.encode_first_stage(vid)
+    finally:
+        torch.randn = orig
+    assert z.shape == g["z"].shape
+    assert rel_l2(z, g["z"]) < 3e-2
+    rec = model.decode_first_stage(T(g["z"]))
+    assert rel_l2(rec, g["rec"]) < 3e-2
+
+
+def test_unet_vs_oracle_odd_sizes():
+    """Oracle comparison on a latent whose row counts are not multiples of the 128-row GEMM tile, T=3, B=1,
+    and a context without per-frame image tokens... exercises tail masking in every kernel."""
+    from dynamicrafter_amd.lvdm.modules.networks.openaimodel3d import UNetModel
+    from oracle import unet as ounet
+    from oracle.weights import fill_state_dict
+    from tests.golden_cfg import TINY_UNET
+    params = dict(TINY_UNET, temporal_length=3)
+    cfg = ounet.UNetCfg.from_params(params)
+    sd = fill_state_dict(ounet.unet_param_shapes(cfg), seed=5)
+    net = UNetModel(**params)
+    net.load_state_dict(sd, strict=True)
+    net.to(DEV)
+    gen = torch.Generator().manual_seed(3)
+    x = torch.randn(1, 8, 3, 24, 8, generator=gen)
+    ctx = torch.randn(1, 77 + 3 * 16, 128, generator=gen)
+    ts = torch.tensor([333])
+    ref = ounet.unet_forward(sd, cfg, x, ts, ctx, None)
+    y = net(x.to(DEV), ts.to(DEV), context=ctx.to(DEV))
+    assert rel_l2(y, ref) < 3e-2 and cosine(y, ref) > 0.999
+
+
+def test_no_cpu_fallback():
+    from dynamicrafter_amd.lvdm.modules.networks.openaimodel3d import UNetModel
+    from tests.golden_cfg import TINY_UNET
+    net = UNetModel(**TINY_UNET)
+    with pytest.raises(RuntimeError):
+        net(torch.zeros(1, 8, 4, 8, 8), torch.zeros(1, dtype=torch.long), context=torch.zeros(1, 141, 128))

@@ -135,7 +135,7 @@ def test_trajectory_matches_reference(tag, disc, eta, gr):
 
 def test_first_stage_matches_reference():
     g = load("first_stage")
-    cfg = ovae.AECfg(ch=32)
+    cfg = ovae.AECfg(ch=64)
     sd = fill_state_dict(ovae.ae_param_shapes(cfg), seed=13)
     sf = float(g["scale_factor"])
     vid = T(g["video"])
