@@ -20,6 +20,73 @@ from .... import ops
 from ..utils_diffusion import make_ddim_sampling_parameters, make_ddim_timesteps
 
 
+class FusedRun:
+    """State of one fused sampling run: the latent (updated in place), device tables / counter, the batched
+    guidance branches, and optionally the captured hipGraph of a step. `step()` advances the device-side DDIM
+    index by one; after `S` steps `rewind()` starts the next clip."""
+
+    def __init__(self, sampler, img, branches, *, fs=None, noises=None, cfg_scale=1.0, cfg_img=None,
+                 guidance_rescale=0.0, temperature=1.0):
+        m = sampler.model
+        self.sampler, self.model = sampler, m
+        self.img = img
+        dev = img.device
+        b = img.shape[0]
+        self.S = sampler._exec_timesteps.shape[0]
+        self.nb = len(branches)
+        self.prep = m.prepare_branches(tuple(img.shape), branches, fs=fs)
+        self.noises = noises
+        self.pred_x0 = torch.empty_like(img)
+        self.ws = torch.empty(16 * b * 256, dtype=torch.float32, device=dev)
+        self.counter = torch.zeros(1, dtype=torch.int32, device=dev)
+        t_host = torch.as_tensor(sampler._exec_timesteps.copy(), dtype=torch.int64)
+        self.t_table = t_host[:, None].repeat(1, self.nb * b).contiguous().to(dev)          # [S, nb*B]
+        self.kw = dict(B=b, Cc=img.shape[1], THW=int(np.prod(img.shape[2:])), v_param=m.parameterization == "v",
+                       cfg_scale=cfg_scale, cfg_img=cfg_scale if cfg_img is None else cfg_img,
+                       guidance_rescale=guidance_rescale, temperature=temperature, noise_step_stride=img.numel())
+        self.graph = None
+
+    def _enqueue(self):
+        """Kernel launches of one step (no allocation, no host sync): batched UNet + fused DDIM update."""
+        e = self.model.apply_model_rows(self.img, self.prep, self.t_table, t_index=self.counter)
+        M = self.kw["B"] * self.kw["THW"]
+        e_u = e[M:2 * M] if self.nb > 1 else None
+        e_i = e[2 * M:3 * M] if self.nb > 2 else None
+        ops.ddim_step(self.sampler._tables, e[:M], e_u, e_i, self.img, self.noises, self.img, self.pred_x0, self.ws,
+                      step_index=self.counter, **self.kw)
+        ops.advance_counter(self.counter)
+
+    def capture(self):
+        """Warm up once eagerly (allocates all scratch), restore the state, capture one step into a hipGraph."""
+        keep = self.img.clone()
+        self._enqueue()
+        torch.cuda.synchronize()
+        self.img.copy_(keep)
+        self.counter.zero_()
+        torch.cuda.synchronize()
+        self.graph = ops.DeviceGraph().capture(self._enqueue)
+        return self
+
+    def step(self):
+        if self.graph is not None:
+            self.graph.launch()
+        else:
+            self._enqueue()
+
+    def rewind(self, x_T=None):
+        self.sync()
+        self.counter.zero_()
+        if x_T is not None:
+            self.img.copy_(x_T)
+        torch.cuda.synchronize()
+
+    def sync(self):
+        if self.graph is not None:
+            self.graph.sync()
+        else:
+            torch.cuda.current_stream().synchronize()
+
+
 class DDIMSampler(object):
     def __init__(self, model, schedule="linear", **kwargs):
         super().__init__()
@@ -127,52 +194,25 @@ class DDIMSampler(object):
             noises = torch.stack([torch.randn(shape, device=dev) for _ in range(S)])
         if noises is not None:
             noises = noises.to(device=dev, dtype=torch.float32).contiguous()
-        v_param = m.parameterization == "v"
-        C_, THW = shape[1], int(np.prod(shape[2:]))
-        pred_x0 = torch.empty_like(img)
-        ws = torch.empty(16 * b * 256, dtype=torch.float32, device=dev)
-        counter = torch.zeros(1, dtype=torch.int32, device=dev)
-        t_host = torch.as_tensor(self._exec_timesteps.copy(), dtype=torch.int64)
-        t_table = t_host[:, None].repeat(1, nb * b).contiguous().to(dev)          # [S, nb*B]
         fast = hasattr(m, "apply_model_rows") and all(isinstance(c, dict) for c in branches)
-        prep = m.prepare_branches(shape, branches, fs=fs) if fast else None
         intermediates = {"x_inter": [img.clone()], "pred_x0": [img.clone()]}
 
-        def one_step():
-            if fast:
-                e = m.apply_model_rows(img, prep, t_table, t_index=counter)
-                M = b * THW
-                e_c, e_u = e[:M], (e[M:2 * M] if nb > 1 else None)
-                e_i = e[2 * M:3 * M] if nb > 2 else None
-                ops.ddim_step(self._tables, e_c, e_u, e_i, img, noises, img, pred_x0, ws, B=b, Cc=C_, THW=THW,
-                              step_index=counter, v_param=v_param, cfg_scale=unconditional_guidance_scale,
-                              cfg_img=cfg_img, guidance_rescale=guidance_rescale, temperature=temperature,
-                              noise_step_stride=img.numel())
-            else:
-                raise RuntimeError("generic model path is handled outside one_step")
-            ops.advance_counter(counter)
-
         if fast and mask is None:
+            run = FusedRun(self, img, branches, fs=fs, noises=noises, cfg_scale=unconditional_guidance_scale,
+                           cfg_img=cfg_img, guidance_rescale=guidance_rescale, temperature=temperature)
             if use_graph:
-                one_step()                                   # eager warm-up: allocates every scratch buffer
-                torch.cuda.synchronize()
-                counter.fill_(1)
-                g = ops.DeviceGraph().capture(one_step)
-                counter.fill_(1)
-                torch.cuda.synchronize()
-                for i in range(1, S):
-                    g.launch()
-                g.sync()
-                self._graph = g
-            else:
-                for i in range(S):
-                    one_step()
+                run.capture()
+            for i in range(S):
+                run.step()
+                if not use_graph:
                     index = S - i - 1
                     if callback: callback(i)
-                    if img_callback: img_callback(pred_x0, i)
+                    if img_callback: img_callback(run.pred_x0, i)
                     if index % log_every_t == 0 or index == S - 1:
                         intermediates["x_inter"].append(img.clone())
-                        intermediates["pred_x0"].append(pred_x0.clone())
+                        intermediates["pred_x0"].append(run.pred_x0.clone())
+            run.sync()
+            self._last_run = run
             return img, intermediates
 
         # generic path: any model exposing apply_model(x, t, c, **kw) -> [B, C, ...] (also mask / x0 blending)

@@ -10,7 +10,7 @@ import torch
 def make_beta_schedule(schedule, n_timestep, linear_start=1e-4, linear_end=2e-2, cosine_s=8e-3):
     if schedule != "linear":
         raise NotImplementedError(f"beta schedule '{schedule}' (the released configs use 'linear')")
-    ramp = torch.linspace(linear_start ** 0.5, linear_end ** 0.5, n_timestep, dtype=torch.float64)
+    ramp = torch.linspace(linear_start ** 0.5, linear_end ** 0.5, n_timestep, dtype=torch.float64, device="cpu")
     return (ramp * ramp).numpy()
 
 

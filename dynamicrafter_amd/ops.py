@@ -19,6 +19,58 @@ def stream_ptr():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+class Tracer:
+    """Per-launch HIP-event timing + algorithmic work accounting (bench.py's roofline leg). While a Tracer is
+    installed (`with Tracer() as tr:`) every heavy op brackets its launch with two hipEvents on the launch stream;
+    `summary()` reduces them per kernel family: launches, total ms, FLOPs, algorithmic HBM bytes."""
+
+    def __init__(self):
+        self.records = []
+
+    def __enter__(self):
+        global _TRACE
+        _TRACE = self
+        return self
+
+    def __exit__(self, *a):
+        global _TRACE
+        _TRACE = None
+
+    def _event(self):
+        e = C.c_void_p()
+        check(_hip.lib().dc_event_create(C.byref(e)), "dc_event_create")
+        return e
+
+    def summary(self):
+        l = _hip.lib()
+        out = {}
+        for name, flops, nbytes, e0, e1 in self.records:
+            ms = C.c_float()
+            check(l.dc_event_elapsed_ms(e0, e1, C.byref(ms)), "dc_event_elapsed_ms")
+            d = out.setdefault(name, dict(launches=0, ms=0.0, flops=0.0, bytes=0.0))
+            d["launches"] += 1; d["ms"] += ms.value; d["flops"] += flops; d["bytes"] += nbytes
+            l.dc_event_destroy(e0); l.dc_event_destroy(e1)
+        self.records = []
+        return out
+
+
+_TRACE = None
+
+
+def _launch(name, flops, nbytes, fn, *args):
+    tr = _TRACE
+    if tr is None:
+        check(fn(*args), name)
+        return
+    l = _hip.lib()
+    e0, e1 = tr._event(), tr._event()
+    sp = stream_ptr()
+    l.dc_event_record(e0, sp)
+    check(fn(*args), name)
+    l.dc_event_record(e1, sp)
+    tr.records.append((name, flops, nbytes, e0, e1))
+
+
 def _ptr(t):
     return C.c_void_p(0 if t is None else t.data_ptr())
 
@@ -34,11 +86,12 @@ class PackedWeight:
     """Device copy of a Linear / conv weight in the layout dc_gemm_conv consumes: bf16 [n_pad][K], K ordered
     (tap, ci), rows zero-padded to a multiple of 128. Derived from the nn.Parameter, never serialised."""
 
-    __slots__ = ("w", "bias", "N", "K", "n_pad", "Cin", "taps")
+    __slots__ = ("w", "bias", "N", "K", "n_pad", "Cin", "taps", "k_real")
 
-    def __init__(self, w, bias, N, K, Cin, taps):
+    def __init__(self, w, bias, N, K, Cin, taps, k_real=None):
         self.w, self.bias, self.N, self.K, self.Cin, self.taps = w, bias, N, K, Cin, taps
         self.n_pad = w.shape[0]
+        self.k_real = k_real        # un-padded reduction length (algorithmic FLOP accounting)
 
     @staticmethod
     def _finish(w2d, bias, device, Cin, taps, pad_n_to=None):
@@ -80,7 +133,9 @@ class PackedWeight:
             w = torch.nn.functional.pad(w, (0, 0, 0, npad - co))
             if bias is not None:
                 bias = torch.nn.functional.pad(bias.detach(), (0, npad - co))
-        return PackedWeight._finish(w, bias, device, cip, 9)
+        pw = PackedWeight._finish(w, bias, device, cip, 9)
+        pw.k_real = 9 * ci
+        return pw
 
     @staticmethod
     def tconv3(weight, bias, device):
@@ -133,7 +188,17 @@ def gemm(a, pw, out, *, M=None, residual=None, rowvec=None, rows_per_vec=1, gegl
     n_out = pw.N // 2 if geglu else pw.N
     if out.shape[1] < n_out:
         raise ValueError(f"gemm: out has {out.shape[1]} columns, need {n_out}")
-    check(_hip.lib().dc_gemm_conv(C.byref(p), stream_ptr()), "dc_gemm_conv")
+    if _TRACE is not None:
+        t128 = (pw.N + 127) // 128 * 128
+        variant = "gemm_conv<128,geglu>" if geglu else ("gemm_conv<64>" if (pw.N <= 64 or t128 / pw.N > 1.15) else "gemm_conv<128>")
+        k_real = pw.k_real if pw.k_real else pw.K
+        flops = 2.0 * p.M * pw.N * k_real
+        esz = 4 if out_f32 else 2
+        nbytes = 2.0 * p.M * (k_real if p.mode == 0 else pw.Cin) + 2.0 * pw.N * pw.K + esz * p.M * n_out \
+            + (2.0 * p.M * n_out if residual is not None else 0)
+        _launch(variant, flops, nbytes, _hip.lib().dc_gemm_conv, C.byref(p), stream_ptr())
+    else:
+        check(_hip.lib().dc_gemm_conv(C.byref(p), stream_ptr()), "dc_gemm_conv")
     return out
 
 
@@ -154,15 +219,16 @@ def groupnorm(x, y, gamma, beta, *, groups, n_inst, rows_per_inst, eps, silu):
     Cc = gamma.numel()
     l = _hip.lib()
     ws = _gn_workspace(x.device, int(l.dc_groupnorm_workspace_bytes(n_inst, groups, rows_per_inst)))
-    check(l.dc_groupnorm(_ptr(x), x.stride(0), _ptr(y), y.stride(0), _ptr(gamma), _ptr(beta), Cc, groups, n_inst,
-                         rows_per_inst, eps, 1 if silu else 0, _ptr(ws), stream_ptr()), "dc_groupnorm")
+    _launch("groupnorm(3 kernels)", 0.0, 6.0 * n_inst * rows_per_inst * Cc, l.dc_groupnorm, _ptr(x), x.stride(0), _ptr(y),
+            y.stride(0), _ptr(gamma), _ptr(beta), Cc, groups, n_inst, rows_per_inst, eps, 1 if silu else 0, _ptr(ws),
+            stream_ptr())
     return y
 
 
 def layernorm(x, y, gamma, beta, eps=1e-5):
     _rows(x, "x"); _rows(y, "y")
-    check(_hip.lib().dc_layernorm(_ptr(x), x.stride(0), _ptr(y), y.stride(0), _ptr(gamma), _ptr(beta), x.shape[0],
-                                  gamma.numel(), eps, stream_ptr()), "dc_layernorm")
+    _launch("layernorm", 0.0, 4.0 * x.shape[0] * gamma.numel(), _hip.lib().dc_layernorm, _ptr(x), x.stride(0), _ptr(y),
+            y.stride(0), _ptr(gamma), _ptr(beta), x.shape[0], gamma.numel(), eps, stream_ptr())
     return y
 
 
@@ -172,17 +238,19 @@ def flash_attn(q, k, v, o, *, batch, heads, Lq, Lk, scale, accumulate=False, acc
     q_bstride / kv_bstride: rows between consecutive batch items (default Lq / Lk)."""
     for t, n in ((q, "q"), (k, "k"), (v, "v"), (o, "o")):
         _rows(t, n)
-    check(_hip.lib().dc_flash_attn_d64(_ptr(q), _ptr(k), _ptr(v), _ptr(o), q.stride(0), k.stride(0), v.stride(0),
-                                       o.stride(0), batch, heads, Lq, Lk, Lq if q_bstride is None else q_bstride,
-                                       Lk if kv_bstride is None else kv_bstride, scale, 1 if accumulate else 0,
-                                       acc_scale, stream_ptr()), "dc_flash_attn_d64")
+    _launch("flash_attn_d64(self)" if Lk > 128 else "flash_attn_d64(cross)", 4.0 * batch * heads * Lq * Lk * 64,
+            2.0 * batch * heads * 64 * (2 * Lq + 2 * Lk), _hip.lib().dc_flash_attn_d64, _ptr(q), _ptr(k), _ptr(v), _ptr(o),
+            q.stride(0), k.stride(0), v.stride(0), o.stride(0), batch, heads, Lq, Lk,
+            Lq if q_bstride is None else q_bstride, Lk if kv_bstride is None else kv_bstride, scale,
+            1 if accumulate else 0, acc_scale, stream_ptr())
     return o
 
 
 def temporal_attn(qkv, o, *, B, T, HW, heads, scale):
     _rows(qkv, "qkv"); _rows(o, "o")
-    check(_hip.lib().dc_temporal_attn_d64(_ptr(qkv), qkv.stride(0), _ptr(o), o.stride(0), B, T, HW, heads, scale,
-                                          stream_ptr()), "dc_temporal_attn_d64")
+    _launch("temporal_attn_d64", 4.0 * B * HW * heads * T * T * 64, 2.0 * B * T * HW * heads * 64 * 4,
+            _hip.lib().dc_temporal_attn_d64, _ptr(qkv), qkv.stride(0), _ptr(o), o.stride(0), B, T, HW, heads, scale,
+            stream_ptr())
     return o
 
 
@@ -221,8 +289,8 @@ def rows_to_nchw(rows, y, *, N, Cc, HW, scale=1.0):
 def copy2d(src, dst, cols=None):
     _rows(src, "src"); _rows(dst, "dst")
     cols = src.shape[1] if cols is None else cols
-    check(_hip.lib().dc_copy2d(_ptr(src), src.stride(0), _ptr(dst), dst.stride(0), src.shape[0], cols, stream_ptr()),
-          "dc_copy2d")
+    _launch("copy2d", 0.0, 4.0 * src.shape[0] * cols, _hip.lib().dc_copy2d, _ptr(src), src.stride(0), _ptr(dst),
+            dst.stride(0), src.shape[0], cols, stream_ptr())
     return dst
 
 
