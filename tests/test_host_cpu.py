@@ -1,0 +1,151 @@
+"""CPU-side tests (no GPU): the C-ABI library loads and exports every declared symbol, host-side schedule logic is
+bit-exact against the reference's golden tables, state_dict keys match the reference's, the registry resolves the
+released YAMLs, and the clip-sharding path works across 2 gloo ranks."""
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+import yaml
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+G = os.path.join(ROOT, "tests", "golden")
+
+
+def test_cabi_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "dcrafter_hip.h")).read()
+    declared = set(re.findall(r"\b(dc_[a-z0-9_]+)\s*\(", hdr))
+    from dynamicrafter_amd import _hip
+    assert declared == set(_hip.SIGNATURES), (declared ^ set(_hip.SIGNATURES))
+    lib = _hip.lib()                       # raises if the .so or any symbol is missing
+    for name in declared:
+        assert hasattr(lib, name)
+    assert lib.dc_version().startswith(b"dcrafter_hip")
+    # exported as plain C symbols (no torch types in the ABI)
+    nm = subprocess.run(["nm", "-D", "--defined-only", _hip.LIB_PATH], capture_output=True, text=True).stdout
+    exported = set(re.findall(r" T (dc_[a-z0-9_]+)", nm))
+    assert declared <= exported
+
+
+def test_cabi_argument_errors_without_gpu():
+    """Bad arguments are rejected before any launch (return codes, no exceptions from C)."""
+    from dynamicrafter_amd import _hip
+    lib = _hip.lib()
+    p = _hip.DcGemmParams()
+    p.M, p.N, p.K = 128, 64, 63            # K not a multiple of 64
+    import ctypes as C
+    assert lib.dc_gemm_conv(C.byref(p), None) == -1
+    assert lib.dc_layernorm(None, 0, None, 0, None, None, 1, 64, 1e-5, None) == -2
+    assert lib.dc_temporal_attn_d64(C.c_void_p(8), 64, C.c_void_p(8), 64, 1, 17, 4, 1, 0.125, None) == -1
+
+
+def _tiny_model(config_name, extra=None):
+    from dynamicrafter_amd.utils.utils import instantiate_from_config
+    from tests.golden_cfg import TINY_AE, TINY_UNET
+    cfg = yaml.safe_load(open(os.path.join(ROOT, "dynamicrafter_amd", "configs", config_name)))
+    p = cfg["model"]["params"]
+    p["unet_config"]["params"] = dict(TINY_UNET, default_fs=p["unet_config"]["params"]["default_fs"], **(extra or {}))
+    p["first_stage_config"]["params"]["ddconfig"] = dict(TINY_AE)
+    for k in ("cond_stage_config", "img_cond_stage_config", "image_proj_stage_config"):
+        p[k] = {"target": "torch.nn.Identity"}
+    return instantiate_from_config(cfg["model"])
+
+
+def test_host_schedules_bit_exact_vs_reference():
+    from dynamicrafter_amd.lvdm.models.samplers.ddim import DDIMSampler
+    g = np.load(os.path.join(G, "schedules.npz"))
+    for tag in ("256", "512", "1024"):
+        m = _tiny_model(f"inference_{tag}_v1.0.yaml")
+        for k in ("betas", "alphas_cumprod", "alphas_cumprod_prev", "sqrt_alphas_cumprod",
+                  "sqrt_one_minus_alphas_cumprod"):
+            assert np.array_equal(getattr(m, k).numpy(), g[f"{tag}/{k}"]), (tag, k)
+        if m.use_dynamic_rescale:
+            assert np.array_equal(m.scale_arr.numpy(), g[f"{tag}/scale_arr"])
+        for S in (10, 50):
+            for disc in ("uniform", "uniform_trailing"):
+                for eta in (0, 1):
+                    s = DDIMSampler(m)
+                    s.make_schedule(S, ddim_discretize=disc, ddim_eta=float(eta), verbose=False)
+                    key = f"{tag}/S{S}/{disc}/eta{eta}"
+                    assert np.array_equal(s.ddim_timesteps, g[key + "/ddim_timesteps"])
+                    for nm in ("a_t", "a_prev", "sigma_t", "sqrt_one_minus_at"):
+                        assert np.array_equal(s._tables[nm].numpy()[::-1], g[f"{key}/{nm}"], equal_nan=True), (key, nm)
+                    if m.use_dynamic_rescale:
+                        assert np.array_equal(s._tables["scale_ratio"].numpy()[::-1],
+                                              g[key + "/scale_prev"] / g[key + "/scale_t"])
+
+
+def test_released_yaml_instantiates_with_reference_keys():
+    """The full 1024 config through the registry; UNet state_dict keys/shapes == the reference's 1516 tensors."""
+    from dynamicrafter_amd.utils.utils import instantiate_from_config
+    cfg = yaml.safe_load(open(os.path.join(ROOT, "dynamicrafter_amd", "configs", "inference_1024_v1.0.yaml")))
+    unet = instantiate_from_config(cfg["model"]["params"]["unet_config"].copy() | {"params": dict(
+        cfg["model"]["params"]["unet_config"]["params"])})
+    g = np.load(os.path.join(G, "unet_fullwidth_8x8.npz"))
+    digest = sorted(f"{k}:{'x'.join(map(str, v.shape))}" for k, v in unet.state_dict().items())
+    assert digest == [str(s) for s in g["key_digest"]]
+    assert sum(p.numel() for p in unet.parameters()) == 1438854980
+    # conditioner placeholders construct but refuse to run
+    enc = instantiate_from_config(cfg["model"]["params"]["cond_stage_config"])
+    with pytest.raises(NotImplementedError):
+        enc(["a prompt"])
+    # reference YAML content is unchanged
+    ref = os.path.join("/root/reference/configs/inference_1024_v1.0.yaml")
+    if os.path.exists(ref):
+        assert yaml.safe_load(open(ref)) == cfg
+
+
+def test_unsupported_configuration_is_loud():
+    from dynamicrafter_amd.lvdm.modules.networks.openaimodel3d import UNetModel
+    from tests.golden_cfg import TINY_UNET
+    with pytest.raises(NotImplementedError):
+        UNetModel(**dict(TINY_UNET, num_head_channels=32))
+    with pytest.raises(NotImplementedError):
+        UNetModel(**dict(TINY_UNET, use_relative_position=True))
+
+
+def test_shard_indices_match_reference_semantics():
+    from dynamicrafter_amd.parallel import shard_indices
+    assert shard_indices(8, 8, 3) == [3]
+    assert shard_indices(10, 4, 0) == [0, 1] and shard_indices(10, 4, 3) == [6, 7]     # tail (8, 9) dropped
+    assert shard_indices(3, 8, 2) == []
+
+
+_WORKER = r'''
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+from dynamicrafter_amd.parallel import scatter_conditioning, gather_clips, shard_indices
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+full = None
+if rank == 0:
+    g = torch.Generator().manual_seed(0)
+    full = {"ctx": torch.randn(4, 333, 16, generator=g), "c_concat": torch.randn(4, 4, 2, 3, 3, generator=g),
+            "fs": torch.arange(4, dtype=torch.int64)}
+mine = scatter_conditioning(full, src=0)
+g = torch.Generator().manual_seed(0)
+ref = {"ctx": torch.randn(4, 333, 16, generator=g), "c_concat": torch.randn(4, 4, 2, 3, 3, generator=g),
+       "fs": torch.arange(4, dtype=torch.int64)}
+idx = shard_indices(4, world, rank)
+for k in ref:
+    assert torch.equal(mine[k], ref[k][idx]), (rank, k)
+out = gather_clips(mine["c_concat"] * 2, dst=0)
+if rank == 0:
+    assert torch.equal(out, ref["c_concat"] * 2)
+dist.barrier()
+print("rank", rank, "ok")
+'''
+
+
+def test_two_rank_scatter_gather_gloo(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29631", str(script), ROOT],
+                       capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert r.stdout.count("ok") == 2
