@@ -8,7 +8,7 @@ HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -I$ROOT/include -I$HERE"
 OBJS=()
 pids=()
-for f in gemm_conv norms attention elementwise runtime; do
+for f in gemm_conv gemm_conv_glds norms attention elementwise runtime; do
   "$HIPCC" $FLAGS -c "$HERE/$f.hip" -o "$HERE/$f.o" &
   pids+=($!)
   OBJS+=("$HERE/$f.o")

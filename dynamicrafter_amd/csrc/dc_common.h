@@ -10,6 +10,7 @@ typedef __attribute__((ext_vector_type(8))) short bf16x8_t;   // one MFMA A/B fr
 typedef __attribute__((ext_vector_type(4))) short bf16x4_t;   // 16x16x16 fragment (2 VGPRs)
 typedef __attribute__((ext_vector_type(16))) float f32x16_t;  // 32x32 accumulator
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;    // 16x16 accumulator
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;  // 16-byte staging register
 
 #define DC_WAVE 64
 

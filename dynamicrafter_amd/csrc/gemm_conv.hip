@@ -18,6 +18,7 @@
 // ds_read_b128 fragment reads.
 #include "dc_common.h"
 #include "dcrafter_hip.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -31,7 +32,11 @@ __device__ __forceinline__ int lds_off(int row, int chunk) {
     return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4);
 }
 
-template <int BN, bool GEGLU>
+// 32 zero bytes in device memory: padded taps / tail rows load from here, so every global load of the main loop is
+// unconditional (a branch around a load makes hipcc wait for it at the join: four serialised round trips per tile).
+__device__ __attribute__((aligned(16))) uint32_t g_zero_chunk[8];
+
+template <int BN, bool GEGLU, int MODE>
 __global__ __launch_bounds__(NTHREADS) void gemm_conv_kernel(const DcGemmParams p) {
     constexpr int NB = BN / 64;              // 32-wide n-blocks per wave
     constexpr int BNOUT = GEGLU ? BN / 2 : BN;
@@ -60,27 +65,32 @@ __global__ __launch_bounds__(NTHREADS) void gemm_conv_kernel(const DcGemmParams 
     const int chunk = tid & 7;        // 16-byte chunk inside the 64-wide K slice
     const int srow = tid >> 3;        // 0..31
     // A rows handled by this thread: srow + 32*i
-    int a_base[4];    // mode 0: row offset (elements) or -1; mode 1: n*IH*IW ; mode 2: row index
-    int a_y[4], a_x[4];
+    const bf16_t* const zero_ptr = reinterpret_cast<const bf16_t*>(g_zero_chunk);
+    const bf16_t* a_ptr[4];   // MODE 0: row base + chunk (k0 added per tile); MODE 2: centre-tap row base + chunk
+    int a_base[4];            // MODE 1: first row of the frame; -1 = row beyond M
+    int a_y[4], a_x[4];       // MODE 1: top-left input coordinate of the window; MODE 2: frame index t
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int m = m0 + srow + 32 * i;
-        if (m >= p.M) { a_base[i] = -1; a_y[i] = 0; a_x[i] = 0; continue; }
-        if (p.mode == 0) {
-            a_base[i] = m; a_y[i] = 0; a_x[i] = 0;
-        } else if (p.mode == 1) {
+        const bool ok = m < p.M;
+        a_base[i] = ok ? 0 : -1;
+        a_y[i] = 0; a_x[i] = 0;
+        a_ptr[i] = zero_ptr;
+        if (MODE == 0) {
+            if (ok) a_ptr[i] = p.A + (size_t)m * p.lda + chunk * 8;
+        } else if (MODE == 1) {
             const int ohw = p.OH * p.OW;
-            const int n = m / ohw;
-            const int rem = m - n * ohw;
+            const int mm = ok ? m : 0;
+            const int n = mm / ohw;
+            const int rem = mm - n * ohw;
             const int oy = rem / p.OW;
             const int ox = rem - oy * p.OW;
-            a_base[i] = n * p.IH * p.IW;
+            if (ok) a_base[i] = n * p.IH * p.IW;
             a_y[i] = oy * p.stride - p.pad;
             a_x[i] = ox * p.stride - p.pad;
         } else {
-            a_base[i] = m;
-            a_y[i] = (m / p.HW) % p.T;   // frame index t
-            a_x[i] = 0;
+            if (ok) a_ptr[i] = p.A + (size_t)m * p.lda + chunk * 8;
+            a_y[i] = ((ok ? m : 0) / p.HW) % p.T;   // frame index t
         }
     }
     // B rows handled by this thread
@@ -97,49 +107,53 @@ __global__ __launch_bounds__(NTHREADS) void gemm_conv_kernel(const DcGemmParams 
         b_ptr[i] = p.W + (size_t)wrow * p.K + chunk * 8;   // W is zero-padded to a multiple of the tile in N
     }
 
-    uint4 a_reg[4], b_reg[B_ITERS];
+    u32x4_t a_reg[4], b_reg[B_ITERS];     // native vectors (HIP's uint4 wrapper struct defeats SROA -> scratch)
     const int nk = p.K / BK;
 
-    auto load_tile = [&](int kt) {
+    auto load_tile = [&](int kt) __attribute__((always_inline)) {
         const int k0 = kt * BK;
-        int tap = 0, ci0 = k0;
-        if (p.mode != 0) { tap = k0 / p.Cin; ci0 = k0 - tap * p.Cin; }
-        int dy = 0, dx = 0;
-        if (p.mode == 1) { dy = tap / 3; dx = tap - dy * 3; }
+        if (MODE == 0) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (a_base[i] >= 0) {
-                if (p.mode == 0) {
-                    v = *reinterpret_cast<const uint4*>(p.A + (size_t)a_base[i] * p.lda + k0 + chunk * 8);
-                } else if (p.mode == 1) {
-                    const int iy = a_y[i] + dy, ix = a_x[i] + dx;
-                    const int eh = p.IH << p.ups, ew = p.IW << p.ups;
-                    if (iy >= 0 && iy < eh && ix >= 0 && ix < ew) {
-                        const int src = a_base[i] + (iy >> p.ups) * p.IW + (ix >> p.ups);
-                        v = *reinterpret_cast<const uint4*>(p.A + (size_t)src * p.lda + ci0 + chunk * 8);
-                    }
-                } else {
-                    const int tt = a_y[i] + tap - 1;
-                    if (tt >= 0 && tt < p.T) {
-                        const int src = a_base[i] + (tap - 1) * p.HW;
-                        v = *reinterpret_cast<const uint4*>(p.A + (size_t)src * p.lda + ci0 + chunk * 8);
-                    }
-                }
+            for (int i = 0; i < 4; ++i) {
+                const bf16_t* src = (a_base[i] >= 0) ? a_ptr[i] + k0 : zero_ptr;
+                a_reg[i] = *reinterpret_cast<const u32x4_t*>(src);
             }
-            a_reg[i] = v;
+        } else if (MODE == 1) {
+            const int tap = k0 / p.Cin;
+            const int ci0 = k0 - tap * p.Cin;
+            const int dy = tap / 3, dx = tap - dy * 3;
+            const int eh = p.IH << p.ups, ew = p.IW << p.ups;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int iy = a_y[i] + dy, ix = a_x[i] + dx;
+                const bool ok = (a_base[i] >= 0) & (iy >= 0) & (iy < eh) & (ix >= 0) & (ix < ew);
+                const int srcrow = a_base[i] + (iy >> p.ups) * p.IW + (ix >> p.ups);
+                const bf16_t* src = ok ? p.A + (size_t)srcrow * p.lda + ci0 + chunk * 8 : zero_ptr;
+                a_reg[i] = *reinterpret_cast<const u32x4_t*>(src);
+            }
+        } else {
+            const int tap = k0 / p.Cin;
+            const int ci0 = k0 - tap * p.Cin;
+            const long long shift = (long long)(tap - 1) * p.HW * p.lda + ci0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int tt = a_y[i] + tap - 1;
+                const bool ok = (a_base[i] >= 0) & (tt >= 0) & (tt < p.T);
+                const bf16_t* src = ok ? a_ptr[i] + shift : zero_ptr;
+                a_reg[i] = *reinterpret_cast<const u32x4_t*>(src);
+            }
         }
 #pragma unroll
-        for (int i = 0; i < B_ITERS; ++i) b_reg[i] = *reinterpret_cast<const uint4*>(b_ptr[i] + k0);
+        for (int i = 0; i < B_ITERS; ++i) b_reg[i] = *reinterpret_cast<const u32x4_t*>(b_ptr[i] + k0);
     };
 
-    auto store_tile = [&](int buf) {
+    auto store_tile = [&](int buf) __attribute__((always_inline)) {
         char* sa = smem + buf * STAGE;
         char* sb = sa + A_BYTES;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) *reinterpret_cast<uint4*>(sa + lds_off(srow + 32 * i, chunk)) = a_reg[i];
+        for (int i = 0; i < 4; ++i) *reinterpret_cast<u32x4_t*>(sa + lds_off(srow + 32 * i, chunk)) = a_reg[i];
 #pragma unroll
-        for (int i = 0; i < B_ITERS; ++i) *reinterpret_cast<uint4*>(sb + lds_off(srow + 32 * i, chunk)) = b_reg[i];
+        for (int i = 0; i < B_ITERS; ++i) *reinterpret_cast<u32x4_t*>(sb + lds_off(srow + 32 * i, chunk)) = b_reg[i];
     };
 
     f32x16_t acc[2][NB];
@@ -157,7 +171,10 @@ __global__ __launch_bounds__(NTHREADS) void gemm_conv_kernel(const DcGemmParams 
     const int fr = lane & 31, fh = lane >> 5;
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
-        if (kt + 1 < nk) load_tile(kt + 1);
+        // unconditional prefetch (the last iteration re-fetches its own tile into the idle buffer): keeping the
+        // loads and the LDS writes out of branches lets the staging registers stay registers (a conditional
+        // prefetch made hipcc spill them to scratch behind a vmcnt wait, serialising every tile on HBM latency)
+        load_tile(kt + 1 < nk ? kt + 1 : kt);
         const char* sa = smem + buf * STAGE;
         const char* sb = sa + A_BYTES;
 #pragma unroll
@@ -179,120 +196,126 @@ __global__ __launch_bounds__(NTHREADS) void gemm_conv_kernel(const DcGemmParams 
                 for (int nb = 0; nb < NB; ++nb)
                     acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[nb], xf[mb], acc[mb][nb], 0, 0, 0);
         }
-        if (kt + 1 < nk) store_tile(buf ^ 1);
+        store_tile(buf ^ 1);
         __syncthreads();
     }
 
     // ---------------- epilogue ----------------
-    // lane holds, for output row m = wm*64 + mb*32 + (lane&31), the channels
-    //   nloc = nb*32 + 8*q + 4*(lane>>5) + {0..3}   (q = 0..3) in acc[mb][nb][4q..4q+3]
+    // Accumulators go through LDS as fp32, half a tile (64 rows) at a time, and come back row-major: every
+    // thread then owns 4 consecutive channels of one row, so bias / embedding-add / GEGLU / residual are 16- or
+    // 8-byte coalesced accesses and nothing is rounded before the final bf16 conversion.
+    // Lane layout of acc[mb][nb]: row m = wm*64 + mb*32 + (lane&31); channels nb*32 + 8*q + 4*(lane>>5) + {0..3}
+    // in registers 4q..4q+3.
     const bool out_f32 = (p.flags & DC_GEMM_OUT_F32) != 0;
-    constexpr int NOUTB = GEGLU ? 1 : NB;   // output n-blocks per wave
-    constexpr int WN_OUT = 32 * NOUTB;      // output columns per wave
-    constexpr int CS_LD = BNOUT * 2 + 8;    // bytes per row of the staging tile (padded: conflict-free b64 writes)
-
-    if (out_f32) {
-#pragma unroll
-        for (int mb = 0; mb < 2; ++mb) {
-            const int m = m0 + wm * 64 + mb * 32 + fr;
-            if (m >= p.M) continue;
-#pragma unroll
-            for (int nb = 0; nb < NOUTB; ++nb)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int n = n0 + wn * WN_OUT + nb * 32 + 8 * q + 4 * fh;
-                    if (n >= n_out) continue;
-                    float v[4];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        float x = acc[mb][nb][4 * q + e];
-                        if (p.bias) x += p.bias[n + e];
-                        if constexpr (GEGLU) {
-                            float g = acc[mb][NB - 1][4 * q + e];
-                            if (p.bias) g += p.bias[(p.N >> 1) + n + e];
-                            x = x * gelu_erf_f(g);
-                        }
-                        v[e] = x * p.alpha;
-                    }
-                    float* dst = reinterpret_cast<float*>(p.C) + (size_t)m * p.ldc + n;
-                    *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
-                }
-        }
-        return;
-    }
-
-    char* cs = smem;   // reuse the pipeline buffers (all waves passed the final barrier of the K loop)
+    constexpr int CS_LD = BNOUT * 4 + 16;       // bytes per staged row (pad keeps b128 writes conflict-free)
+    constexpr int HALF_ROWS = 64;
+    constexpr int XG = GEGLU ? 2 : 1;            // value and gate planes
+    constexpr int PLANE = HALF_ROWS * CS_LD;
+    static_assert(XG * PLANE <= 2 * STAGE, "epilogue staging must fit the pipeline buffers");
+    constexpr int UPR = BNOUT / 4;               // 4-channel units per row
+    constexpr int UNITS = HALF_ROWS * UPR;
+    char* cs = smem;
 #pragma unroll
     for (int mb = 0; mb < 2; ++mb) {
-        const int mloc = wm * 64 + mb * 32 + fr;
-        const int m = m0 + mloc;
-        const float* rv = nullptr;
-        if (p.rowvec && m < p.M) rv = p.rowvec + (size_t)(m / p.rows_per_vec) * p.rowvec_ld;
+        if (mb) __syncthreads();                 // previous half fully read back
+        {
+            const int rloc = wm * 32 + fr;       // row inside the half: waves wm=0 -> 0..31, wm=1 -> 32..63
 #pragma unroll
-        for (int nb = 0; nb < NOUTB; ++nb)
+            for (int nb = 0; nb < NB; ++nb) {
+                const int plane = GEGLU ? nb : 0;
+                const int ncol0 = GEGLU ? wn * 32 : wn * (32 * NB) + nb * 32;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int nloc = wn * WN_OUT + nb * 32 + 8 * q + 4 * fh;
-                const int n = n0 + nloc;
-                float v[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    float x = acc[mb][nb][4 * q + e];
-                    if (n + e < n_out) {
-                        if (p.bias) x += p.bias[n + e];
-                        if constexpr (GEGLU) {
-                            float g = acc[mb][NB - 1][4 * q + e];
-                            if (p.bias) g += p.bias[(p.N >> 1) + n + e];
-                            x = x * gelu_erf_f(g);
-                        }
-                        if (rv) x += rv[n + e];
-                    }
-                    v[e] = x * p.alpha;
+                for (int q = 0; q < 4; ++q) {
+                    const int nloc = ncol0 + 8 * q + 4 * fh;
+                    float4 v = make_float4(acc[mb][nb][4 * q], acc[mb][nb][4 * q + 1], acc[mb][nb][4 * q + 2],
+                                           acc[mb][nb][4 * q + 3]);
+                    *reinterpret_cast<float4*>(cs + plane * PLANE + rloc * CS_LD + nloc * 4) = v;
                 }
-                uint2 pk;
-                pk.x = pack_bf2(v[0], v[1]);
-                pk.y = pack_bf2(v[2], v[3]);
-                *reinterpret_cast<uint2*>(cs + mloc * CS_LD + nloc * 2) = pk;
             }
-    }
-    __syncthreads();
-    constexpr int UPR = BNOUT / 4;            // 8-byte units per row
-    constexpr int UNITS = BM * UPR;
-    bf16_t* cptr = reinterpret_cast<bf16_t*>(p.C);
-#pragma unroll
-    for (int i = 0; i < UNITS / NTHREADS; ++i) {
-        const int u = tid + NTHREADS * i;
-        const int r = u / UPR;
-        const int c = (u - r * UPR) * 4;
-        const int m = m0 + r, n = n0 + c;
-        if (m >= p.M || n >= n_out) continue;
-        uint2 pk = *reinterpret_cast<const uint2*>(cs + r * CS_LD + c * 2);
-        if (p.residual) {
-            const uint2 rr = *reinterpret_cast<const uint2*>(p.residual + (size_t)m * p.ldr + n);
-            float a0 = __uint_as_float(pk.x << 16) + __uint_as_float(rr.x << 16);
-            float a1 = __uint_as_float(pk.x & 0xffff0000u) + __uint_as_float(rr.x & 0xffff0000u);
-            float a2 = __uint_as_float(pk.y << 16) + __uint_as_float(rr.y << 16);
-            float a3 = __uint_as_float(pk.y & 0xffff0000u) + __uint_as_float(rr.y & 0xffff0000u);
-            pk.x = pack_bf2(a0, a1);
-            pk.y = pack_bf2(a2, a3);
         }
-        *reinterpret_cast<uint2*>(cptr + (size_t)m * p.ldc + n) = pk;
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < UNITS / NTHREADS; ++i) {
+            const int u = tid + NTHREADS * i;
+            const int r = u / UPR;
+            const int c = (u - r * UPR) * 4;
+            // half-row r belongs to wave-row wm = r / 32: global row = m0 + wm*64 + mb*32 + (r % 32)
+            const int m = m0 + (r >> 5) * 64 + mb * 32 + (r & 31);
+            const int n = n0 + c;
+            if (m >= p.M || n >= n_out) continue;
+            float4 v = *reinterpret_cast<const float4*>(cs + r * CS_LD + c * 4);
+            if (p.bias) {
+                const float4 bv = *reinterpret_cast<const float4*>(p.bias + n);
+                v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+            }
+            if constexpr (GEGLU) {
+                float4 g = *reinterpret_cast<const float4*>(cs + PLANE + r * CS_LD + c * 4);
+                if (p.bias) {
+                    const float4 bg = *reinterpret_cast<const float4*>(p.bias + (p.N >> 1) + n);
+                    g.x += bg.x; g.y += bg.y; g.z += bg.z; g.w += bg.w;
+                }
+                v.x *= gelu_erf_f(g.x); v.y *= gelu_erf_f(g.y); v.z *= gelu_erf_f(g.z); v.w *= gelu_erf_f(g.w);
+            }
+            if (p.rowvec) {
+                const float4 rv = *reinterpret_cast<const float4*>(p.rowvec + (size_t)(m / p.rows_per_vec) * p.rowvec_ld + n);
+                v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
+            }
+            v.x *= p.alpha; v.y *= p.alpha; v.z *= p.alpha; v.w *= p.alpha;
+            if (out_f32) {
+                *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.C) + (size_t)m * p.ldc + n) = v;
+            } else {
+                // bf16 rounding, then the residual add (as the reference adds two already-rounded tensors)
+                uint2 pk;
+                pk.x = pack_bf2(v.x, v.y);
+                pk.y = pack_bf2(v.z, v.w);
+                if (p.residual) {
+                    const uint2 rr = *reinterpret_cast<const uint2*>(p.residual + (size_t)m * p.ldr + n);
+                    const float a0 = __uint_as_float(pk.x << 16) + __uint_as_float(rr.x << 16);
+                    const float a1 = __uint_as_float(pk.x & 0xffff0000u) + __uint_as_float(rr.x & 0xffff0000u);
+                    const float a2 = __uint_as_float(pk.y << 16) + __uint_as_float(rr.y << 16);
+                    const float a3 = __uint_as_float(pk.y & 0xffff0000u) + __uint_as_float(rr.y & 0xffff0000u);
+                    pk.x = pack_bf2(a0, a1);
+                    pk.y = pack_bf2(a2, a3);
+                }
+                *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.C) + (size_t)m * p.ldc + n) = pk;
+            }
+        }
     }
 }
 
-template <int BN, bool GEGLU>
-int launch(const DcGemmParams& p, hipStream_t stream) {
+template <int BN, bool GEGLU, int MODE>
+int launch_mode(const DcGemmParams& p, hipStream_t stream) {
     constexpr int BNOUT = GEGLU ? BN / 2 : BN;
     const int n_out = GEGLU ? p.N / 2 : p.N;
     const int tiles_n = (n_out + BNOUT - 1) / BNOUT;
     const int tiles_m = (p.M + BM - 1) / BM;
     const size_t lds = 2 * (BM * BK * 2 + BN * BK * 2);
-    hipLaunchKernelGGL((gemm_conv_kernel<BN, GEGLU>), dim3(tiles_m * tiles_n), dim3(NTHREADS), lds, stream, p);
+    hipLaunchKernelGGL((gemm_conv_kernel<BN, GEGLU, MODE>), dim3(tiles_m * tiles_n), dim3(NTHREADS), lds, stream, p);
     DC_CHECK_LAUNCH();
     return 0;
 }
 
+template <int BN, bool GEGLU>
+int launch(const DcGemmParams& p, hipStream_t stream) {
+    if (p.mode == 0) return launch_mode<BN, GEGLU, 0>(p, stream);
+    if (GEGLU) return DC_ERR_ARG;
+    if (p.mode == 1) return launch_mode<BN, false, 1>(p, stream);
+    if (p.mode == 2) return launch_mode<BN, false, 2>(p, stream);
+    return DC_ERR_ARG;
+}
+
 }  // namespace
+
+int dc_gemm_conv_glds_try(const DcGemmParams& p, hipStream_t stream);   // gemm_conv_glds.hip
+
+static bool glds_enabled() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("DC_GEMM_GLDS");
+        v = (e && e[0] == '0') ? 0 : 1;
+    }
+    return v == 1;
+}
 
 extern "C" int dc_gemm_conv(const DcGemmParams* pp, void* stream_) {
     const DcGemmParams& p = *pp;
@@ -304,11 +327,13 @@ extern "C" int dc_gemm_conv(const DcGemmParams* pp, void* stream_) {
     if (p.mode == 2 && p.K != 3 * p.Cin) return DC_ERR_SHAPE;
     if (p.residual && (p.ldr % 4 != 0)) return DC_ERR_SHAPE;
     const bool geglu = (p.flags & DC_GEMM_GEGLU) != 0;
-    if (geglu) {
-        if ((p.N / 2) % 64 != 0) return DC_ERR_SHAPE;
-        if (p.n_pad < p.N) return DC_ERR_SHAPE;
-        return launch<128, true>(p, stream);
+    if (geglu && ((p.N / 2) % 64 != 0 || p.n_pad < p.N)) return DC_ERR_SHAPE;
+    if (p.n_pad < (p.N + 127) / 128 * 128) return DC_ERR_SHAPE;
+    if (glds_enabled()) {                      // big launches: 256-row LDS-DMA pipeline
+        const int r = dc_gemm_conv_glds_try(p, stream);
+        if (r != -100) return r;
     }
+    if (geglu) return launch<128, true>(p, stream);
     // Tile choice: 128-wide N tiles unless that wastes >15% of the MFMA work on padding (N = 320 -> 64-wide).
     const int t128 = (p.N + 127) / 128 * 128;
     const bool use64 = (p.N <= 64) || ((float)t128 / (float)p.N > 1.15f);

@@ -1,0 +1,338 @@
+// Large-tile variant of dc_gemm_conv for the big-M launches: 256 x BN x 64 tiles, 8 waves (4 x 2), operands staged
+// HBM/L2 -> LDS by LDS-DMA (global_load_lds_dwordx4, no VGPR round trip, no ds_write), a 3-stage LDS ring with two
+// K tiles in flight behind a counted s_waitcnt vmcnt(N) and ONE raw s_barrier per K tile.
+//
+// Why a second kernel: PMC on the 128-row register-staged kernel (profiles/) shows the MFMA pipe busy 33 % of the
+// time with waves parked on the per-tile vmcnt(0)+barrier (32 %) and issue stalls (31 %): its prefetch distance is
+// one tile and every staged byte costs a ds_write_b128 (13 cycles per wave instruction).
+//
+// LDS-DMA is issued from inline asm on purpose: hipcc tracks builtin LDS-DMA as pending LDS writes and puts
+// s_waitcnt vmcnt(0) in front of the next ds_read, draining the ring every K step. The asm form is invisible to
+// that pass, so the waits are counted by hand here (N = glds per wave per tile x tiles left in flight); the only
+// compiler-counted vector-memory operations of this kernel are in the epilogue, after a full drain.
+// The LDS image is the same XOR-swizzled [row][8 x 16 B] layout as the small kernel; since LDS-DMA writes
+// lane-linear (base + lane*16), the swizzle is applied to the per-lane SOURCE address.
+#include "dc_common.h"
+#include "dcrafter_hip.h"
+#include <stdlib.h>
+
+namespace {
+
+constexpr int GBM = 256;
+constexpr int GBK = 64;
+constexpr int GNT = 512;
+constexpr int GSTAGES = 3;
+
+typedef __attribute__((address_space(3))) char lds_char_t;
+
+__device__ __attribute__((aligned(16))) uint32_t g_zero_chunk2[8];
+
+__device__ __forceinline__ int lds_off2(int row, int chunk) {
+    return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4);
+}
+
+// one wave instruction: 64 lanes x 16 B -> LDS [lds_dst, lds_dst + 1024), lane-linear
+__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst_uniform) {
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %2\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, off\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(gsrc), "s"(lds_dst_uniform)
+        : "memory");
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <int BN, bool GEGLU, int MODE>
+__global__ __launch_bounds__(GNT) void gemm_conv_glds_kernel(const DcGemmParams p) {
+    constexpr int NB = BN / 64;
+    constexpr int BNOUT = GEGLU ? BN / 2 : BN;
+    constexpr int A_BYTES = GBM * GBK * 2;
+    constexpr int B_BYTES = BN * GBK * 2;
+    constexpr int STAGE = A_BYTES + B_BYTES;
+    constexpr int A_IT = 4;                 // glds per wave per tile for A: 256 rows * 8 chunks / 512 lanes
+    constexpr int B_IT = BN / 64;           // for B
+    constexpr int LOADS = A_IT + B_IT;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+
+    const int n_out = GEGLU ? (p.N >> 1) : p.N;
+    const int tiles_n = (n_out + BNOUT - 1) / BNOUT;
+    const int tiles_m = (p.M + GBM - 1) / GBM;
+    const int nwg = tiles_m * tiles_n;
+    const int swz = xcd_remap(blockIdx.x, nwg);
+    const int tile_n = swz % tiles_n;
+    const int tile_m = swz / tiles_n;
+    const int m0 = tile_m * GBM;
+    const int n0 = tile_n * BNOUT;
+
+    const unsigned lds_base = (unsigned)(unsigned long)((lds_char_t*)smem);
+    const bf16_t* const zero_ptr = reinterpret_cast<const bf16_t*>(g_zero_chunk2);
+
+    // ---- staging coordinates: wave instruction j covers LDS slots (j*8 + wave)*64 + lane; slot = row*8 + phys chunk
+    const int srow = lane >> 3;                       // row inside the 8-row group of this instruction
+    const int pchunk = lane & 7;
+    const bf16_t* a_ptr[A_IT];
+    int a_base[A_IT], a_y[A_IT], a_x[A_IT];
+#pragma unroll
+    for (int j = 0; j < A_IT; ++j) {
+        const int r = (j * 8 + wave) * 8 + srow;      // 0..255
+        const int chunk = pchunk ^ ((r >> 1) & 7);    // logical 16-byte chunk this lane must fetch
+        const int m = m0 + r;
+        const bool ok = m < p.M;
+        a_base[j] = ok ? 0 : -1;
+        a_y[j] = 0; a_x[j] = 0;
+        a_ptr[j] = zero_ptr;
+        if (MODE == 0) {
+            if (ok) a_ptr[j] = p.A + (size_t)m * p.lda + chunk * 8;
+        } else if (MODE == 1) {
+            const int ohw = p.OH * p.OW;
+            const int mm = ok ? m : 0;
+            const int n = mm / ohw;
+            const int rem = mm - n * ohw;
+            const int oy = rem / p.OW;
+            const int ox = rem - oy * p.OW;
+            if (ok) a_base[j] = n * p.IH * p.IW;
+            a_y[j] = oy * p.stride - p.pad;
+            a_x[j] = ox * p.stride - p.pad;
+            a_ptr[j] = p.A + chunk * 8;               // + row*lda + ci0 per tile
+        } else {
+            if (ok) a_ptr[j] = p.A + (size_t)m * p.lda + chunk * 8;
+            a_y[j] = ((ok ? m : 0) / p.HW) % p.T;
+        }
+    }
+    const bf16_t* b_ptr[B_IT];
+#pragma unroll
+    for (int j = 0; j < B_IT; ++j) {
+        const int r = (j * 8 + wave) * 8 + srow;      // row inside the B tile
+        const int chunk = pchunk ^ ((r >> 1) & 7);
+        int wrow;
+        if (GEGLU) wrow = (r < BN / 2) ? (n0 + r) : ((p.N >> 1) + n0 + (r - BN / 2));
+        else wrow = n0 + r;
+        b_ptr[j] = p.W + (size_t)wrow * p.K + chunk * 8;
+    }
+
+    const int nk = p.K / GBK;
+
+    auto issue_tile = [&](int kt, int stage) __attribute__((always_inline)) {
+        const int k0 = kt * GBK;
+        const unsigned sa = lds_base + stage * STAGE;
+        const unsigned sb = sa + A_BYTES;
+        if (MODE == 0) {
+#pragma unroll
+            for (int j = 0; j < A_IT; ++j) {
+                const bf16_t* src = (a_base[j] >= 0) ? a_ptr[j] + k0 : zero_ptr;
+                glds16(src, sa + (j * 8 + wave) * 1024);
+            }
+        } else if (MODE == 1) {
+            const int tap = k0 / p.Cin;
+            const int ci0 = k0 - tap * p.Cin;
+            const int dy = tap / 3, dx = tap - dy * 3;
+            const int eh = p.IH << p.ups, ew = p.IW << p.ups;
+#pragma unroll
+            for (int j = 0; j < A_IT; ++j) {
+                const int iy = a_y[j] + dy, ix = a_x[j] + dx;
+                const bool ok = (a_base[j] >= 0) & (iy >= 0) & (iy < eh) & (ix >= 0) & (ix < ew);
+                const int srcrow = a_base[j] + (iy >> p.ups) * p.IW + (ix >> p.ups);
+                const bf16_t* src = ok ? a_ptr[j] + (size_t)srcrow * p.lda + ci0 : zero_ptr;
+                glds16(src, sa + (j * 8 + wave) * 1024);
+            }
+        } else {
+            const int tap = k0 / p.Cin;
+            const int ci0 = k0 - tap * p.Cin;
+            const long long shift = (long long)(tap - 1) * p.HW * p.lda + ci0;
+#pragma unroll
+            for (int j = 0; j < A_IT; ++j) {
+                const int tt = a_y[j] + tap - 1;
+                const bool ok = (a_base[j] >= 0) & (tt >= 0) & (tt < p.T);
+                const bf16_t* src = ok ? a_ptr[j] + shift : zero_ptr;
+                glds16(src, sa + (j * 8 + wave) * 1024);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < B_IT; ++j) glds16(b_ptr[j] + k0, sb + (j * 8 + wave) * 1024);
+    };
+
+    f32x16_t acc[2][NB];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NB; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    issue_tile(0, 0);
+    if (nk > 1) issue_tile(1, 1);
+
+    const int fr = lane & 31, fh = lane >> 5;
+    int stage = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+        // tile kt has landed when at most the younger tile's LOADS remain outstanding
+        if (kt + 1 < nk) wait_vmcnt<LOADS>(); else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();        // everyone's share of tile kt is in LDS; everyone is done with tile kt-1
+        asm volatile("" ::: "memory");
+        if (kt + 2 < nk) {
+            int s2 = stage + 2; if (s2 >= GSTAGES) s2 -= GSTAGES;
+            issue_tile(kt + 2, s2);
+        }
+        const char* sa = smem + stage * STAGE;
+        const char* sb = sa + A_BYTES;
+#pragma unroll
+        for (int kk = 0; kk < GBK / 16; ++kk) {
+            bf16x8_t xf[2], wf[NB];
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb)
+                xf[mb] = *reinterpret_cast<const bf16x8_t*>(sa + lds_off2(wm * 64 + mb * 32 + fr, kk * 2 + fh));
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) {
+                int brow;
+                if (GEGLU) brow = nb * (BN / 2) + wn * 32 + fr;
+                else brow = wn * (32 * NB) + nb * 32 + fr;
+                wf[nb] = *reinterpret_cast<const bf16x8_t*>(sb + lds_off2(brow, kk * 2 + fh));
+            }
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb)
+                    acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[nb], xf[mb], acc[mb][nb], 0, 0, 0);
+        }
+        ++stage; if (stage >= GSTAGES) stage = 0;
+    }
+    wait_vmcnt<0>();
+    __syncthreads();                         // all fragment reads done before the ring is reused for the epilogue
+
+    // ---------------- epilogue: fp32 through LDS in two halves of 128 rows, coalesced row-major read-back
+    const bool out_f32 = (p.flags & DC_GEMM_OUT_F32) != 0;
+    constexpr int CS_LD = BNOUT * 4 + 16;
+    constexpr int HALF_ROWS = 128;
+    constexpr int XG = GEGLU ? 2 : 1;
+    constexpr int PLANE = HALF_ROWS * CS_LD;
+    static_assert(XG * PLANE <= GSTAGES * STAGE, "epilogue staging must fit the ring");
+    constexpr int UPR = BNOUT / 4;
+    constexpr int UNITS = HALF_ROWS * UPR;
+    char* cs = smem;
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb) {
+        if (mb) __syncthreads();
+        {
+            const int rloc = wm * 32 + fr;            // 0..127
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) {
+                const int plane = GEGLU ? nb : 0;
+                const int ncol0 = GEGLU ? wn * 32 : wn * (32 * NB) + nb * 32;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int nloc = ncol0 + 8 * q + 4 * fh;
+                    float4 v = make_float4(acc[mb][nb][4 * q], acc[mb][nb][4 * q + 1], acc[mb][nb][4 * q + 2],
+                                           acc[mb][nb][4 * q + 3]);
+                    *reinterpret_cast<float4*>(cs + plane * PLANE + rloc * CS_LD + nloc * 4) = v;
+                }
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < UNITS / GNT; ++i) {
+            const int u = tid + GNT * i;
+            const int r = u / UPR;
+            const int c = (u - r * UPR) * 4;
+            const int m = m0 + (r >> 5) * 64 + mb * 32 + (r & 31);
+            const int n = n0 + c;
+            if (m >= p.M || n >= n_out) continue;
+            float4 v = *reinterpret_cast<const float4*>(cs + r * CS_LD + c * 4);
+            if (p.bias) {
+                const float4 bv = *reinterpret_cast<const float4*>(p.bias + n);
+                v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+            }
+            if constexpr (GEGLU) {
+                float4 g = *reinterpret_cast<const float4*>(cs + PLANE + r * CS_LD + c * 4);
+                if (p.bias) {
+                    const float4 bg = *reinterpret_cast<const float4*>(p.bias + (p.N >> 1) + n);
+                    g.x += bg.x; g.y += bg.y; g.z += bg.z; g.w += bg.w;
+                }
+                v.x *= gelu_erf_f(g.x); v.y *= gelu_erf_f(g.y); v.z *= gelu_erf_f(g.z); v.w *= gelu_erf_f(g.w);
+            }
+            if (p.rowvec) {
+                const float4 rv = *reinterpret_cast<const float4*>(p.rowvec + (size_t)(m / p.rows_per_vec) * p.rowvec_ld + n);
+                v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
+            }
+            v.x *= p.alpha; v.y *= p.alpha; v.z *= p.alpha; v.w *= p.alpha;
+            if (out_f32) {
+                *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.C) + (size_t)m * p.ldc + n) = v;
+            } else {
+                uint2 pk;
+                pk.x = pack_bf2(v.x, v.y);
+                pk.y = pack_bf2(v.z, v.w);
+                if (p.residual) {
+                    const uint2 rr = *reinterpret_cast<const uint2*>(p.residual + (size_t)m * p.ldr + n);
+                    const float a0 = __uint_as_float(pk.x << 16) + __uint_as_float(rr.x << 16);
+                    const float a1 = __uint_as_float(pk.x & 0xffff0000u) + __uint_as_float(rr.x & 0xffff0000u);
+                    const float a2 = __uint_as_float(pk.y << 16) + __uint_as_float(rr.y << 16);
+                    const float a3 = __uint_as_float(pk.y & 0xffff0000u) + __uint_as_float(rr.y & 0xffff0000u);
+                    pk.x = pack_bf2(a0, a1);
+                    pk.y = pack_bf2(a2, a3);
+                }
+                *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.C) + (size_t)m * p.ldc + n) = pk;
+            }
+        }
+    }
+}
+
+template <int BN, bool GEGLU, int MODE>
+int launch_glds(const DcGemmParams& p, hipStream_t stream) {
+    constexpr int BNOUT = GEGLU ? BN / 2 : BN;
+    const int n_out = GEGLU ? p.N / 2 : p.N;
+    const int tiles_n = (n_out + BNOUT - 1) / BNOUT;
+    const int tiles_m = (p.M + GBM - 1) / GBM;
+    constexpr size_t lds = (size_t)GSTAGES * (GBM * GBK * 2 + BN * GBK * 2);
+    static bool configured = false;
+    if (!configured) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_conv_glds_kernel<BN, GEGLU, MODE>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+        configured = true;
+    }
+    hipLaunchKernelGGL((gemm_conv_glds_kernel<BN, GEGLU, MODE>), dim3(tiles_m * tiles_n), dim3(GNT), lds, stream, p);
+    DC_CHECK_LAUNCH();
+    return 0;
+}
+
+}  // namespace
+
+// Returns -100 when this variant does not apply (caller falls back to the 128-row kernel).
+int dc_gemm_conv_glds_try(const DcGemmParams& p, hipStream_t stream) {
+    const bool geglu = (p.flags & DC_GEMM_GEGLU) != 0;
+    const int n_out = geglu ? p.N / 2 : p.N;
+    const int tiles_m = (p.M + GBM - 1) / GBM;
+    if (geglu) {
+        if (p.mode != 0) return DC_ERR_ARG;
+        if (tiles_m * (n_out / 64) < 384) return -100;
+        return launch_glds<128, true, 0>(p, stream);
+    }
+    const int t128 = (p.N + 127) / 128 * 128;
+    const bool use64 = (p.N <= 64) || ((float)t128 / (float)p.N > 1.15f);
+    const int tiles_n = use64 ? (p.N + 63) / 64 : t128 / 128;
+    if (tiles_m * tiles_n < 384) return -100;       // too few 256-row tiles to fill 256 CUs: keep 128-row tiles
+    // 64-wide N tiles (N = 320): a 256x64 tile stages 40 KB per 2.1 MFLOP and measured slower than the 128-row
+    // register-staged kernel at 2 workgroups/CU (rocprof: 1040 vs 890 us on conv 320->320 @72x128)
+    static const bool glds64 = [] { const char* e = getenv("DC_GEMM_GLDS64"); return e && e[0] == '1'; }();
+    if (use64 && !glds64) return -100;
+    if (use64) {
+        if (p.mode == 0) return launch_glds<64, false, 0>(p, stream);
+        if (p.mode == 1) return launch_glds<64, false, 1>(p, stream);
+        return launch_glds<64, false, 2>(p, stream);
+    }
+    if (p.mode == 0) return launch_glds<128, false, 0>(p, stream);
+    if (p.mode == 1) return launch_glds<128, false, 1>(p, stream);
+    return launch_glds<128, false, 2>(p, stream);
+}

@@ -267,3 +267,55 @@ def test_softmax_and_vae_sample(ops):
     mean, logvar = m[:, :4], torch.clamp(m[:, 4:], -30, 20)
     ref = 0.18215 * (mean + torch.exp(0.5 * logvar) * noise)
     assert rel_l2(z, ref) < 1e-5
+
+
+# ---- large launches: these shapes take the 256-row LDS-DMA pipeline (gemm_conv_glds.hip) --------------------
+@pytest.mark.parametrize("M,N,K", [(25600, 512, 320), (20480 + 77, 320, 640), (30000, 448, 192), (131072, 64, 64)])
+def test_gemm_plain_large(ops, M, N, K):
+    x = bf(rnd(M, K, seed=1)); w = rnd(N, K, seed=2, scale=K ** -0.5); b = rnd(N, seed=3)
+    res = bf(rnd(M, N, seed=4)); rv = rnd(4, N, seed=5)
+    pw = ops.PackedWeight.linear(w, b, DEV)
+    out = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+    rpv = (M + 3) // 4
+    ops.gemm(x.to(DEV), pw, out, residual=res.to(DEV), rowvec=rv.to(DEV), rows_per_vec=rpv)
+    ref = x.float() @ bf(w).float().t() + b + rv.repeat_interleave(rpv, 0)[:M]
+    ref = bf(ref).float() + res.float()
+    assert rel_l2(out, ref) < 4e-3
+    out32 = torch.empty(M, N, dtype=torch.float32, device=DEV)
+    ops.gemm(x.to(DEV), pw, out32, alpha=0.25)
+    assert rel_l2(out32, 0.25 * (x.float() @ bf(w).float().t() + b)) < 2e-5
+
+
+def test_gemm_geglu_large(ops):
+    M, dim, inner = 25600 + 33, 128, 512
+    x = bf(rnd(M, dim, seed=1)); w = rnd(2 * inner, dim, seed=2, scale=dim ** -0.5); b = rnd(2 * inner, seed=3, scale=0.1)
+    pw = ops.PackedWeight.linear(w, b, DEV)
+    out = torch.empty(M, inner, dtype=torch.bfloat16, device=DEV)
+    ops.gemm(x.to(DEV), pw, out, geglu=True)
+    h = x.float() @ bf(w).float().t() + b
+    val, gate = h.chunk(2, dim=-1)
+    assert rel_l2(out, val * F.gelu(gate)) < 4e-3
+
+
+@pytest.mark.parametrize("cfg", [
+    dict(n=32, C=64, Co=256, H=40, W=40, stride=1, pad=1, ups=0),
+    dict(n=30, C=128, Co=320, H=33, W=47, stride=1, pad=1, ups=0),      # ragged rows, N=320 (64-wide tiles)
+    dict(n=32, C=64, Co=256, H=20, W=20, stride=1, pad=1, ups=1),       # fused nearest x2
+    dict(n=32, C=64, Co=256, H=80, W=80, stride=2, pad=1, ups=0),       # stride 2
+])
+def test_conv3x3_large(ops, cfg):
+    test_conv3x3(ops, cfg)
+
+
+def test_tconv3_large(ops):
+    B, T, HW, Cc = 2, 16, 1601, 256
+    x = bf(rnd(B, Cc, T, HW, 1, seed=1)); w = rnd(Cc, Cc, 3, 1, 1, seed=2, scale=(3 * Cc) ** -0.5); b = rnd(Cc, seed=3)
+    ref = F.conv3d(x.float(), bf(w).float(), b, padding=(1, 0, 0))
+    pw = ops.PackedWeight.tconv3(w, b, DEV)
+    rows = x.permute(0, 2, 3, 4, 1).reshape(-1, Cc).contiguous().to(DEV)
+    res = bf(rnd(rows.shape[0], Cc, seed=9))
+    out = torch.empty_like(rows)
+    ops.gemm(rows, pw, out, tconv=dict(T=T, HW=HW), residual=res.to(DEV))
+    got = out.float().cpu()
+    ref_rows = bf(ref.permute(0, 2, 3, 4, 1).reshape(-1, Cc)).float() + res.float()
+    assert rel_l2(got, ref_rows) < 4e-3

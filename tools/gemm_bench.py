@@ -1,0 +1,74 @@
+"""Micro-benchmark of dc_gemm_conv on the UNet's dominant shapes (batch-2 CFG rows).
+usage: python tools/gemm_bench.py [--iters 20]"""
+import argparse
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from dynamicrafter_amd import ops  # noqa: E402
+from dynamicrafter_amd.ops import PackedWeight  # noqa: E402
+
+DEV = "cuda:0"
+F = 32  # frames (B=2 x T=16)
+SHAPES = [
+    # name, kind, M or (H,W), Cin, Cout
+    ("lin 320x320 L0", "lin", 294912, 320, 320),
+    ("lin 640x640 L1", "lin", 73728, 640, 640),
+    ("lin 1280x1280 L2", "lin", 18432, 1280, 1280),
+    ("ffout 1280->320 L0", "lin", 294912, 1280, 320),
+    ("geglu 320->2560 L0", "geglu", 294912, 320, 2560),
+    ("geglu 1280->10240 L2", "geglu", 18432, 1280, 10240),
+    ("conv3x3 320->320 72x128", "conv", (72, 128), 320, 320),
+    ("conv3x3 640->640 36x64", "conv", (36, 64), 640, 640),
+    ("conv3x3 1280->1280 18x32", "conv", (18, 32), 1280, 1280),
+    ("conv3x3 2560->1280 18x32", "conv", (18, 32), 2560, 1280),
+    ("conv3x3 1280->1280 9x16", "conv", (9, 16), 1280, 1280),
+    ("tconv 320 72x128", "tconv", (72, 128), 320, 320),
+    ("tconv 1280 18x32", "tconv", (18, 32), 1280, 1280),
+]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--iters", type=int, default=20)
+    args = ap.parse_args()
+    for name, kind, m, ci, co in SHAPES:
+        if kind in ("lin", "geglu"):
+            M = m
+            x = torch.randn(M, ci, device=DEV).to(torch.bfloat16)
+            pw = PackedWeight.linear(torch.randn(co, ci) * ci ** -0.5, torch.randn(co), DEV)
+            out = torch.empty(M, co // 2 if kind == "geglu" else co, dtype=torch.bfloat16, device=DEV)
+            kw = dict(geglu=(kind == "geglu"))
+            flops = 2.0 * M * co * ci
+        elif kind == "conv":
+            H, W = m
+            M = F * H * W
+            x = torch.randn(M, ci, device=DEV).to(torch.bfloat16)
+            pw = PackedWeight.conv3x3(torch.randn(co, ci, 3, 3) * (9 * ci) ** -0.5, torch.randn(co), DEV)
+            out = torch.empty(M, co, dtype=torch.bfloat16, device=DEV)
+            kw = dict(conv=dict(IH=H, IW=W, OH=H, OW=W, stride=1, pad=1, ups=0))
+            flops = 2.0 * M * co * ci * 9
+        else:
+            H, W = m
+            M = F * H * W
+            x = torch.randn(M, ci, device=DEV).to(torch.bfloat16)
+            pw = PackedWeight.tconv3(torch.randn(co, ci, 3, 1, 1) * (3 * ci) ** -0.5, torch.randn(co), DEV)
+            out = torch.empty(M, co, dtype=torch.bfloat16, device=DEV)
+            kw = dict(tconv=dict(T=16, HW=H * W))
+            flops = 2.0 * M * co * ci * 3
+        for _ in range(3):
+            ops.gemm(x, pw, out, **kw)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.iters):
+            ops.gemm(x, pw, out, **kw)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / args.iters
+        print(f"{name:28s} M={M:7d} {dt * 1e6:9.1f} us  {flops / dt / 1e12:7.1f} TF/s", flush=True)
+
+
+if __name__ == "__main__":
+    main()
