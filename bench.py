@@ -116,11 +116,19 @@ def main():
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
     import torch.distributed as dist
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    # DC_BENCH_BACKEND=gloo + DC_BENCH_SHARE_GPU=1 rehearse the N>1 code path on a one-GPU box (all ranks on cuda:0,
+    # collectives on CPU tensors); the real launch uses RCCL ("nccl") with one GPU per rank.
+    backend = os.environ.get("DC_BENCH_BACKEND", "nccl")
+    dev_index = 0 if os.environ.get("DC_BENCH_SHARE_GPU") == "1" else local_rank
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=device)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
+    coll_dev = device if backend == "nccl" else torch.device("cpu")
 
     from dynamicrafter_amd import _hip, ops
     from dynamicrafter_amd.lvdm.models.samplers.ddim import DDIMSampler, FusedRun
@@ -133,9 +141,11 @@ def main():
     h, w = LATENT[res]
     T, S = 16, 50
     inp = synth_inputs(res, device, seed=7)
-    if world > 1:                                            # conditioning scattered once from rank 0 (RCCL/xGMI)
+    if world > 1:                                            # conditioning broadcast once from rank 0 (RCCL/xGMI)
         for k in ("cond_ctx", "uc_ctx", "c_concat"):
-            dist.broadcast(inp[k], src=0)
+            buf = inp[k].to(coll_dev)
+            dist.broadcast(buf, src=0)
+            inp[k] = buf.to(device)
     cond = {"c_crossattn": [inp["cond_ctx"]], "c_concat": [inp["c_concat"]]}
     uc = {"c_crossattn": [inp["uc_ctx"]], "c_concat": [inp["c_concat"]]}
     fs = torch.tensor([10], dtype=torch.long, device=device)
@@ -179,7 +189,7 @@ def main():
     ev_ms = C.c_float()
     l.dc_event_elapsed_ms(e0, e1, C.byref(ev_ms))
     if world > 1:
-        tt = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        tt = torch.tensor([elapsed], device=coll_dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = tt.item()
     ms_per_step = elapsed / args.steps * 1e3
@@ -253,6 +263,10 @@ def main():
                     r["frac_hbm"] = round(r["gbs"] / HBM_PEAK_GBS, 4)
                 rows.append(r)
             roof["per_kernel_eager_step"] = rows
+            if os.environ.get("DC_BENCH_DETAIL"):
+                for (name, tag), v in sorted(tr.detail.items(), key=lambda kv: -kv[1]["ms"])[:40]:
+                    log(f"  {name:22s} mode,M,N,K={tag}  x{v['launches']:3d}  {v['ms']:8.3f} ms  "
+                        f"{v['flops'] / (v['ms'] * 1e-3) / 1e12:7.1f} TF/s")
             dom = rows[0]
             roof["dominant_kernel"] = {"name": dom["kernel"], "avg_launch_us": dom["avg_us"],
                                        "achieved": dom.get("tflops", dom.get("gbs")),

@@ -21,7 +21,9 @@ namespace {
 constexpr int GBM = 256;
 constexpr int GBK = 64;
 constexpr int GNT = 512;
-constexpr int GSTAGES = 3;
+// Tile shapes (BN x stages): 128 x 3, 256 x 2 and 320 x 2. The wider tiles exist because the per-CU vector-memory
+// path moves 64 B/clk: a 256x128x64 tile stages 48 KB per 1024 MFMA-cycles per SIMD (47 B/clk, 3/4 of that path),
+// 256x256 31 B/clk, 256x320 28 B/clk. 320 = the UNet's channel quantum (N = 320, 640, 1280, 2560 tile exactly).
 
 typedef __attribute__((address_space(3))) char lds_char_t;
 
@@ -50,9 +52,9 @@ __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <int BN, bool GEGLU, int MODE>
+template <int BN, bool GEGLU, int MODE, int GSTAGES>
 __global__ __launch_bounds__(GNT) void gemm_conv_glds_kernel(const DcGemmParams p) {
-    constexpr int NB = BN / 64;
+    constexpr int NB = BN / 64;             // 32-wide n-blocks per wave (waves are 4 (M) x 2 (N))
     constexpr int BNOUT = GEGLU ? BN / 2 : BN;
     constexpr int A_BYTES = GBM * GBK * 2;
     constexpr int B_BYTES = BN * GBK * 2;
@@ -60,6 +62,8 @@ __global__ __launch_bounds__(GNT) void gemm_conv_glds_kernel(const DcGemmParams 
     constexpr int A_IT = 4;                 // glds per wave per tile for A: 256 rows * 8 chunks / 512 lanes
     constexpr int B_IT = BN / 64;           // for B
     constexpr int LOADS = A_IT + B_IT;
+    static_assert(GSTAGES == 2 || GSTAGES == 3, "ring depth");
+    static_assert(!GEGLU || (NB % 2 == 0), "GEGLU needs value and gate blocks per wave");
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x;
@@ -173,18 +177,18 @@ __global__ __launch_bounds__(GNT) void gemm_conv_glds_kernel(const DcGemmParams 
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     issue_tile(0, 0);
-    if (nk > 1) issue_tile(1, 1);
+    if (GSTAGES == 3 && nk > 1) issue_tile(1, 1);
 
     const int fr = lane & 31, fh = lane >> 5;
     int stage = 0;
     for (int kt = 0; kt < nk; ++kt) {
-        // tile kt has landed when at most the younger tile's LOADS remain outstanding
-        if (kt + 1 < nk) wait_vmcnt<LOADS>(); else wait_vmcnt<0>();
+        // tile kt has landed when at most the younger in-flight tile's LOADS remain outstanding
+        if (GSTAGES == 3 && kt + 1 < nk) wait_vmcnt<LOADS>(); else wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();        // everyone's share of tile kt is in LDS; everyone is done with tile kt-1
         asm volatile("" ::: "memory");
-        if (kt + 2 < nk) {
-            int s2 = stage + 2; if (s2 >= GSTAGES) s2 -= GSTAGES;
-            issue_tile(kt + 2, s2);
+        if (kt + GSTAGES - 1 < nk) {
+            int s2 = stage + GSTAGES - 1; if (s2 >= GSTAGES) s2 -= GSTAGES;
+            issue_tile(kt + GSTAGES - 1, s2);
         }
         const char* sa = smem + stage * STAGE;
         const char* sb = sa + A_BYTES;
@@ -197,45 +201,54 @@ __global__ __launch_bounds__(GNT) void gemm_conv_glds_kernel(const DcGemmParams 
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb) {
                 int brow;
-                if (GEGLU) brow = nb * (BN / 2) + wn * 32 + fr;
-                else brow = wn * (32 * NB) + nb * 32 + fr;
-                wf[nb] = *reinterpret_cast<const bf16x8_t*>(sb + lds_off2(brow, kk * 2 + fh));
+                if (GEGLU) brow = (nb < NB / 2 ? 0 : BN / 2) + wn * (BN / 4) + (nb % (NB / 2 > 0 ? NB / 2 : 1)) * 32;
+                else brow = wn * (32 * NB) + nb * 32;
+                wf[nb] = *reinterpret_cast<const bf16x8_t*>(sb + lds_off2(brow + fr, kk * 2 + fh));
             }
+            __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
                 for (int nb = 0; nb < NB; ++nb)
                     acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[nb], xf[mb], acc[mb][nb], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
         }
         ++stage; if (stage >= GSTAGES) stage = 0;
     }
     wait_vmcnt<0>();
     __syncthreads();                         // all fragment reads done before the ring is reused for the epilogue
 
-    // ---------------- epilogue: fp32 through LDS in two halves of 128 rows, coalesced row-major read-back
+    // ---------------- epilogue: fp32 through LDS, four passes (mb x wave column), coalesced row-major read-back.
+    // Pass (mb, ws): the four waves with wn == ws stage acc[mb][*] for their 128 rows; then every thread reads back
+    // 4 consecutive channels of one row and applies bias / GEGLU / embedding add / alpha / residual.
     const bool out_f32 = (p.flags & DC_GEMM_OUT_F32) != 0;
-    constexpr int CS_LD = BNOUT * 4 + 16;
-    constexpr int HALF_ROWS = 128;
+    constexpr int PCOLS = BNOUT / 2;             // output columns staged per pass
+    constexpr int CS_LD = PCOLS * 4 + 16;
+    constexpr int PROWS = 128;
     constexpr int XG = GEGLU ? 2 : 1;
-    constexpr int PLANE = HALF_ROWS * CS_LD;
+    constexpr int PLANE = PROWS * CS_LD;
     static_assert(XG * PLANE <= GSTAGES * STAGE, "epilogue staging must fit the ring");
-    constexpr int UPR = BNOUT / 4;
-    constexpr int UNITS = HALF_ROWS * UPR;
+    constexpr int UPR = PCOLS / 4;
+    constexpr int UNITS = PROWS * UPR;
+    static_assert(UNITS % GNT == 0, "read-back units per thread");
+    constexpr int NBX = GEGLU ? NB / 2 : NB;     // value blocks per wave
     char* cs = smem;
 #pragma unroll
-    for (int mb = 0; mb < 2; ++mb) {
-        if (mb) __syncthreads();
-        {
+    for (int pass = 0; pass < 4; ++pass) {
+        const int mb = pass >> 1, ws = pass & 1;
+        if (pass) __syncthreads();
+        if (wn == ws) {
             const int rloc = wm * 32 + fr;            // 0..127
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb) {
-                const int plane = GEGLU ? nb : 0;
-                const int ncol0 = GEGLU ? wn * 32 : wn * (32 * NB) + nb * 32;
+                const int plane = (GEGLU && nb >= NBX) ? 1 : 0;
+                const int ncol0 = (GEGLU ? (nb % NBX) : nb) * 32;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const int nloc = ncol0 + 8 * q + 4 * fh;
-                    float4 v = make_float4(acc[mb][nb][4 * q], acc[mb][nb][4 * q + 1], acc[mb][nb][4 * q + 2],
-                                           acc[mb][nb][4 * q + 3]);
+                    float4 v;
+                    if (mb == 0) v = make_float4(acc[0][nb][4 * q], acc[0][nb][4 * q + 1], acc[0][nb][4 * q + 2], acc[0][nb][4 * q + 3]);
+                    else v = make_float4(acc[1][nb][4 * q], acc[1][nb][4 * q + 1], acc[1][nb][4 * q + 2], acc[1][nb][4 * q + 3]);
                     *reinterpret_cast<float4*>(cs + plane * PLANE + rloc * CS_LD + nloc * 4) = v;
                 }
             }
@@ -247,7 +260,7 @@ __global__ __launch_bounds__(GNT) void gemm_conv_glds_kernel(const DcGemmParams 
             const int r = u / UPR;
             const int c = (u - r * UPR) * 4;
             const int m = m0 + (r >> 5) * 64 + mb * 32 + (r & 31);
-            const int n = n0 + c;
+            const int n = n0 + ws * PCOLS + c;
             if (m >= p.M || n >= n_out) continue;
             float4 v = *reinterpret_cast<const float4*>(cs + r * CS_LD + c * 4);
             if (p.bias) {
@@ -288,7 +301,7 @@ __global__ __launch_bounds__(GNT) void gemm_conv_glds_kernel(const DcGemmParams 
     }
 }
 
-template <int BN, bool GEGLU, int MODE>
+template <int BN, bool GEGLU, int MODE, int GSTAGES>
 int launch_glds(const DcGemmParams& p, hipStream_t stream) {
     constexpr int BNOUT = GEGLU ? BN / 2 : BN;
     const int n_out = GEGLU ? p.N / 2 : p.N;
@@ -297,42 +310,58 @@ int launch_glds(const DcGemmParams& p, hipStream_t stream) {
     constexpr size_t lds = (size_t)GSTAGES * (GBM * GBK * 2 + BN * GBK * 2);
     static bool configured = false;
     if (!configured) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_conv_glds_kernel<BN, GEGLU, MODE>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_conv_glds_kernel<BN, GEGLU, MODE, GSTAGES>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
         configured = true;
     }
-    hipLaunchKernelGGL((gemm_conv_glds_kernel<BN, GEGLU, MODE>), dim3(tiles_m * tiles_n), dim3(GNT), lds, stream, p);
+    hipLaunchKernelGGL((gemm_conv_glds_kernel<BN, GEGLU, MODE, GSTAGES>), dim3(tiles_m * tiles_n), dim3(GNT), lds, stream, p);
     DC_CHECK_LAUNCH();
     return 0;
 }
 
+template <int BN, int GSTAGES>
+int launch_glds_mode(const DcGemmParams& p, hipStream_t stream) {
+    if (p.mode == 0) return launch_glds<BN, false, 0, GSTAGES>(p, stream);
+    if (p.mode == 1) return launch_glds<BN, false, 1, GSTAGES>(p, stream);
+    return launch_glds<BN, false, 2, GSTAGES>(p, stream);
+}
+
+// fraction of the chip's workgroup slots a grid of `wgs` one-per-CU workgroups keeps busy
+inline float wave_eff(int wgs) { return (float)wgs / (float)(((wgs + 255) / 256) * 256); }
+
 }  // namespace
 
-// Returns -100 when this variant does not apply (caller falls back to the 128-row kernel).
+// Returns -100 when no large-tile variant applies (caller falls back to the 128-row kernel).
 int dc_gemm_conv_glds_try(const DcGemmParams& p, hipStream_t stream) {
     const bool geglu = (p.flags & DC_GEMM_GEGLU) != 0;
     const int n_out = geglu ? p.N / 2 : p.N;
     const int tiles_m = (p.M + GBM - 1) / GBM;
+    static const int force = [] { const char* e = getenv("DC_GEMM_TILE"); return e ? atoi(e) : 0; }();
     if (geglu) {
         if (p.mode != 0) return DC_ERR_ARG;
-        if (tiles_m * (n_out / 64) < 384) return -100;
-        return launch_glds<128, true, 0>(p, stream);
+        const int w256 = (n_out % 128 == 0 && p.n_pad >= p.N) ? tiles_m * (n_out / 128) : 0;
+        const int w128 = tiles_m * (n_out / 64);
+        if ((force == 256 || (force == 0 && w256 >= 512 && wave_eff(w256) > 0.8f)) && w256 > 0)
+            return launch_glds<256, true, 0, 2>(p, stream);
+        if (w128 < 384) return -100;
+        return launch_glds<128, true, 0, 3>(p, stream);
     }
-    const int t128 = (p.N + 127) / 128 * 128;
-    const bool use64 = (p.N <= 64) || ((float)t128 / (float)p.N > 1.15f);
-    const int tiles_n = use64 ? (p.N + 63) / 64 : t128 / 128;
-    if (tiles_m * tiles_n < 384) return -100;       // too few 256-row tiles to fill 256 CUs: keep 128-row tiles
-    // 64-wide N tiles (N = 320): a 256x64 tile stages 40 KB per 2.1 MFLOP and measured slower than the 128-row
-    // register-staged kernel at 2 workgroups/CU (rocprof: 1040 vs 890 us on conv 320->320 @72x128)
-    static const bool glds64 = [] { const char* e = getenv("DC_GEMM_GLDS64"); return e && e[0] == '1'; }();
-    if (use64 && !glds64) return -100;
-    if (use64) {
-        if (p.mode == 0) return launch_glds<64, false, 0>(p, stream);
-        if (p.mode == 1) return launch_glds<64, false, 1>(p, stream);
-        return launch_glds<64, false, 2>(p, stream);
-    }
-    if (p.mode == 0) return launch_glds<128, false, 0>(p, stream);
-    if (p.mode == 1) return launch_glds<128, false, 1>(p, stream);
-    return launch_glds<128, false, 2>(p, stream);
+    // candidates: 320-wide (exact for the UNet widths), 128-wide; relative MFMA-side efficiency estimates measured on
+    // conv shapes: 320-wide ~1.25x the 128-wide tile when both fill the chip
+    const int t128 = (p.N + 127) / 128;
+    const bool n320 = (p.N % 320 == 0) && (p.n_pad >= p.N);
+    const int w320 = n320 ? tiles_m * (p.N / 320) : 0;
+    const int w128 = tiles_m * t128;
+    const float waste128 = (float)(t128 * 128) / (float)p.N;
+    float s320 = n320 ? 1.25f * wave_eff(w320) : 0.f;
+    float s128 = wave_eff(w128) / waste128;
+    if (w320 < 200) s320 = 0.f;
+    if (w128 < 384) s128 = 0.f;
+    if (force == 320 && n320) return launch_glds_mode<320, 2>(p, stream);
+    if (force == 128 && w128 > 0 && waste128 <= 1.15f) return launch_glds_mode<128, 3>(p, stream);
+    if (force == 1) return -100;
+    if (s320 > 0.f && s320 >= s128) return launch_glds_mode<320, 2>(p, stream);
+    if (s128 > 0.f && waste128 <= 1.15f) return launch_glds_mode<128, 3>(p, stream);
+    return -100;
 }

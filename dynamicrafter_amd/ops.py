@@ -44,11 +44,15 @@ class Tracer:
     def summary(self):
         l = _hip.lib()
         out = {}
-        for name, flops, nbytes, e0, e1 in self.records:
+        self.detail = {}
+        for name, flops, nbytes, e0, e1, tag in self.records:
             ms = C.c_float()
             check(l.dc_event_elapsed_ms(e0, e1, C.byref(ms)), "dc_event_elapsed_ms")
             d = out.setdefault(name, dict(launches=0, ms=0.0, flops=0.0, bytes=0.0))
             d["launches"] += 1; d["ms"] += ms.value; d["flops"] += flops; d["bytes"] += nbytes
+            if tag is not None:
+                dd = self.detail.setdefault((name, tag), dict(launches=0, ms=0.0, flops=0.0))
+                dd["launches"] += 1; dd["ms"] += ms.value; dd["flops"] += flops
             l.dc_event_destroy(e0); l.dc_event_destroy(e1)
         self.records = []
         return out
@@ -57,7 +61,7 @@ class Tracer:
 _TRACE = None
 
 
-def _launch(name, flops, nbytes, fn, *args):
+def _launch(name, flops, nbytes, fn, *args, tag=None):
     tr = _TRACE
     if tr is None:
         check(fn(*args), name)
@@ -68,7 +72,7 @@ def _launch(name, flops, nbytes, fn, *args):
     l.dc_event_record(e0, sp)
     check(fn(*args), name)
     l.dc_event_record(e1, sp)
-    tr.records.append((name, flops, nbytes, e0, e1))
+    tr.records.append((name, flops, nbytes, e0, e1, tag))
 
 
 def _ptr(t):
@@ -196,7 +200,8 @@ def gemm(a, pw, out, *, M=None, residual=None, rowvec=None, rows_per_vec=1, gegl
         esz = 4 if out_f32 else 2
         nbytes = 2.0 * p.M * (k_real if p.mode == 0 else pw.Cin) + 2.0 * pw.N * pw.K + esz * p.M * n_out \
             + (2.0 * p.M * n_out if residual is not None else 0)
-        _launch(variant, flops, nbytes, _hip.lib().dc_gemm_conv, C.byref(p), stream_ptr())
+        _launch(variant, flops, nbytes, _hip.lib().dc_gemm_conv, C.byref(p), stream_ptr(),
+                tag=(p.mode, p.M, pw.N, k_real))
     else:
         check(_hip.lib().dc_gemm_conv(C.byref(p), stream_ptr()), "dc_gemm_conv")
     return out

@@ -319,3 +319,40 @@ def test_tconv3_large(ops):
     got = out.float().cpu()
     ref_rows = bf(ref.permute(0, 2, 3, 4, 1).reshape(-1, Cc)).float() + res.float()
     assert rel_l2(got, ref_rows) < 4e-3
+
+
+# ---- 256x320 / 256x256 LDS-DMA tiles (2-stage ring) --------------------------------------------------------
+@pytest.mark.parametrize("M,N,K", [(51200 + 100, 320, 128), (25600 + 7, 640, 320), (52000, 1280, 64)])
+def test_gemm_plain_320_tiles(ops, M, N, K):
+    test_gemm_plain_large(ops, M, N, K)
+
+
+def test_gemm_geglu_256_tile(ops):
+    M, dim, inner = 32768 - 19, 128, 512
+    x = bf(rnd(M, dim, seed=1)); w = rnd(2 * inner, dim, seed=2, scale=dim ** -0.5); b = rnd(2 * inner, seed=3, scale=0.1)
+    pw = ops.PackedWeight.linear(w, b, DEV)
+    out = torch.empty(M, inner, dtype=torch.bfloat16, device=DEV)
+    ops.gemm(x.to(DEV), pw, out, geglu=True)
+    h = x.float() @ bf(w).float().t() + b
+    val, gate = h.chunk(2, dim=-1)
+    assert rel_l2(out, val * F.gelu(gate)) < 4e-3
+
+
+@pytest.mark.parametrize("cfg", [
+    dict(n=36, C=128, Co=320, H=33, W=47, stride=1, pad=1, ups=0),
+    dict(n=32, C=64, Co=640, H=20, W=20, stride=1, pad=1, ups=1),
+    dict(n=32, C=64, Co=320, H=81, W=80, stride=2, pad=1, ups=0),
+])
+def test_conv3x3_320_tiles(ops, cfg):
+    test_conv3x3(ops, cfg)
+
+
+def test_tconv3_320_tile(ops):
+    B, T, HW, Cc = 2, 16, 1601, 320
+    x = bf(rnd(B, Cc, T, HW, 1, seed=1)); w = rnd(Cc, Cc, 3, 1, 1, seed=2, scale=(3 * Cc) ** -0.5); b = rnd(Cc, seed=3)
+    ref = F.conv3d(x.float(), bf(w).float(), b, padding=(1, 0, 0))
+    pw = ops.PackedWeight.tconv3(w, b, DEV)
+    rows = x.permute(0, 2, 3, 4, 1).reshape(-1, Cc).contiguous().to(DEV)
+    out = torch.empty_like(rows)
+    ops.gemm(rows, pw, out, tconv=dict(T=T, HW=HW))
+    assert rel_l2(out, ref.permute(0, 2, 3, 4, 1).reshape(-1, Cc)) < 4e-3
