@@ -59,28 +59,26 @@ __global__ __launch_bounds__(256) void flash_attn_d64_kernel(
 
     // ---- staging coordinates: 64 rows x 8 chunks per tensor, 2 rows per thread
     const int chunk = tid & 7, srow = tid >> 3;
-    uint4 kreg[2], vreg[2];
-    auto load_tile = [&](int t) {
+    u32x4_t kreg[2], vreg[2];
+    // Unconditional loads: rows past Lk are clamped to the last key (finite data). Their scores are masked to
+    // -1e30 below, so P = 0 there and a finite V contributes exactly 0 — no zero fill, no branch around a load.
+    auto load_tile = [&](int t) __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            const int j = t * FA_BKV + srow + 32 * i;
-            if (j < Lk) {
-                kreg[i] = *reinterpret_cast<const uint4*>(kb + (size_t)j * ldk + chunk * 8);
-                vreg[i] = *reinterpret_cast<const uint4*>(vb + (size_t)j * ldv + chunk * 8);
-            } else {
-                kreg[i] = make_uint4(0, 0, 0, 0);
-                vreg[i] = make_uint4(0, 0, 0, 0);
-            }
+            int j = t * FA_BKV + srow + 32 * i;
+            j = j < Lk ? j : Lk - 1;
+            kreg[i] = *reinterpret_cast<const u32x4_t*>(kb + (size_t)j * ldk + chunk * 8);
+            vreg[i] = *reinterpret_cast<const u32x4_t*>(vb + (size_t)j * ldv + chunk * 8);
         }
     };
-    auto store_tile = [&](int buf) {
+    auto store_tile = [&](int buf) __attribute__((always_inline)) {
         char* sk = smem + buf * FA_STAGE;
         char* sv = sk + FA_KBYTES;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int r = srow + 32 * i;
-            *reinterpret_cast<uint4*>(sk + k_lds_off(r, chunk)) = kreg[i];
-            *reinterpret_cast<uint4*>(sv + r * V_LD + chunk * 16) = vreg[i];
+            *reinterpret_cast<u32x4_t*>(sk + k_lds_off(r, chunk)) = kreg[i];
+            *reinterpret_cast<u32x4_t*>(sv + r * V_LD + chunk * 16) = vreg[i];
         }
     };
 
@@ -103,7 +101,7 @@ __global__ __launch_bounds__(256) void flash_attn_d64_kernel(
 
     for (int t = 0; t < nt; ++t) {
         const int buf = t & 1;
-        if (t + 1 < nt) load_tile(t + 1);
+        load_tile(t + 1 < nt ? t + 1 : t);               // unconditional prefetch (keeps staging in registers)
         const char* sk = smem + buf * FA_STAGE;
         const char* sv = sk + FA_KBYTES;
 
@@ -130,16 +128,25 @@ __global__ __launch_bounds__(256) void flash_attn_d64_kernel(
                 }
         }
         // online softmax: this lane owns query row `fr`; its partner (lane ^ 32) holds the other keys
-        float mx = s[0][0];
+        float mx = fmaxf(fmaxf(s[0][0], s[0][1]), s[0][2]);
 #pragma unroll
-        for (int jb = 0; jb < 2; ++jb)
+        for (int r = 3; r < 15; r += 2) mx = fmaxf(fmaxf(mx, s[0][r]), s[0][r + 1]);
+        mx = fmaxf(mx, s[0][15]);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[jb][r]);
+        for (int r = 0; r < 16; r += 2) mx = fmaxf(fmaxf(mx, s[1][r]), s[1][r + 1]);
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const float m_new = fmaxf(m_run, mx);
-        const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
-        const float mc = m_new * c;
-        m_run = m_new;
+        // rescale only when some row's running max actually grew (alpha == 1 exactly otherwise: skipping is exact)
+        if (__any(mx > m_run)) {
+            const float m_new = fmaxf(m_run, mx);
+            const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
+            m_run = m_new;
+            l_run *= alpha;
+#pragma unroll
+            for (int d = 0; d < 2; ++d)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) oacc[d][r] *= alpha;
+        }
+        const float mc = m_run * c;
         float psum = 0.f;
 #pragma unroll
         for (int jb = 0; jb < 2; ++jb)
@@ -149,24 +156,17 @@ __global__ __launch_bounds__(256) void flash_attn_d64_kernel(
                 s[jb][r] = p;
                 psum += p;
             }
-        l_run = l_run * alpha + psum;
-#pragma unroll
-        for (int d = 0; d < 2; ++d)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) oacc[d][r] *= alpha;
+        l_run += psum;
 
         // O^T[db] += V^T[db][keys] P^T[keys]
 #pragma unroll
         for (int jb = 0; jb < 2; ++jb)
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
-                bf16x8_t pf;
+                u32x4_t pw;
 #pragma unroll
-                for (int e = 0; e < 8; e += 2) {
-                    const uint32_t pk = pack_bf2(s[jb][8 * ks + e], s[jb][8 * ks + e + 1]);
-                    pf[e] = (short)(pk & 0xffff);
-                    pf[e + 1] = (short)(pk >> 16);
-                }
+                for (int e = 0; e < 4; ++e) pw[e] = pack_bf2(s[jb][8 * ks + 2 * e], s[jb][8 * ks + 2 * e + 1]);
+                const bf16x8_t pf = __builtin_bit_cast(bf16x8_t, pw);
                 const int jbase = jb * 32 + 16 * ks + 4 * fh;
 #pragma unroll
                 for (int db = 0; db < 2; ++db) {
@@ -179,7 +179,7 @@ __global__ __launch_bounds__(256) void flash_attn_d64_kernel(
                     oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, oacc[db], 0, 0, 0);
                 }
             }
-        if (t + 1 < nt) store_tile(buf ^ 1);
+        store_tile(buf ^ 1);
         __syncthreads();
     }
 

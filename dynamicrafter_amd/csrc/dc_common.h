@@ -18,17 +18,18 @@ __device__ __forceinline__ float bf2f(bf16_t v) {
     return __uint_as_float(((uint32_t)v) << 16);
 }
 
-// round-to-nearest-even fp32 -> bf16; NaN stays NaN (quiet)
-__device__ __forceinline__ bf16_t f2bf(float f) {
-    uint32_t u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (bf16_t)(u >> 16);
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_hw_t;
+
+// fp32 -> bf16, round-to-nearest-even, NaN stays NaN: a plain vector convert, which hipcc lowers to ONE
+// v_cvt_pk_bf16_f32 per pair on gfx950 (the integer-arithmetic form costs ~8 VALU ops per element and is what made
+// the attention kernel VALU-bound).
+__device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) {
+    const f32x2_t v = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_hw_t));
 }
 
-__device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) {
-    return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
-}
+__device__ __forceinline__ bf16_t f2bf(float f) { return (bf16_t)(pack_bf2(f, 0.f) & 0xffffu); }
 
 __device__ __forceinline__ void unpack_bf8(const uint4& v, float* f) {
     f[0] = __uint_as_float(v.x << 16); f[1] = __uint_as_float(v.x & 0xffff0000u);
