@@ -301,6 +301,219 @@ __global__ __launch_bounds__(GNT) void gemm_conv_glds_kernel(const DcGemmParams 
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Persistent variant for plain GEMMs (mode 0): one workgroup per CU walks a sequence of output tiles and treats
+// their K tiles as ONE stream through the LDS ring, so the LDS-DMA of the next output tile is already in flight
+// while the current one finishes and runs its epilogue. The short-K linears of the UNet (K = 320 / 640: 5-10 K
+// tiles) are latency-bound otherwise: every output tile paid a cold prologue, K sequential waits and an epilogue
+// with nothing in flight (measured 250 us for [294912 x 320 x 320], HBM floor ~110 us).
+// The epilogue goes straight from the accumulators to global memory (8-byte pieces; no LDS: the ring is busy).
+// vmcnt bookkeeping: DMA is counted by hand (asm); the epilogue's loads/stores are compiler-counted. Retirement
+// is in issue order, and every compiler-visible operation is issued AFTER the DMA it could be confused with is
+// already older than the hand-counted window, so each counted wait can only over-wait, never under-wait.
+template <int BN, bool GEGLU, int GSTAGES>
+__global__ __launch_bounds__(GNT) void gemm_persist_kernel(const DcGemmParams p) {
+    constexpr int NB = BN / 64;
+    constexpr int NBX = GEGLU ? NB / 2 : NB;
+    constexpr int BNOUT = GEGLU ? BN / 2 : BN;
+    constexpr int WCOLS = BNOUT / 2;            // output columns per wave
+    constexpr int A_BYTES = GBM * GBK * 2;
+    constexpr int B_BYTES = BN * GBK * 2;
+    constexpr int STAGE = A_BYTES + B_BYTES;
+    constexpr int A_IT = 4;
+    constexpr int B_IT = BN / 64;
+    constexpr int LOADS = A_IT + B_IT;
+    static_assert(GSTAGES >= 2 && GSTAGES <= 4, "ring depth");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int fr = lane & 31, fh = lane >> 5;
+
+    const int n_out = GEGLU ? (p.N >> 1) : p.N;
+    const int tiles_n = (n_out + BNOUT - 1) / BNOUT;
+    const int tiles_m = (p.M + GBM - 1) / GBM;
+    const int ntiles = tiles_m * tiles_n;
+    const int G = gridDim.x;
+    const int nj = (ntiles - (int)blockIdx.x + G - 1) / G;      // output tiles of this workgroup
+    const int nk = p.K / GBK;
+    const int total = nj * nk;
+
+    const unsigned lds_base = (unsigned)(unsigned long)((lds_char_t*)smem);
+    const bf16_t* const zero_ptr = reinterpret_cast<const bf16_t*>(g_zero_chunk2);
+    const int srow = lane >> 3;
+    const int pchunk = lane & 7;
+
+    // ---- issue side: descriptors of the tile whose K tiles are being requested
+    const bf16_t* a_ptr[A_IT];
+    const bf16_t* b_ptr[B_IT];
+    int i_tile = 0, i_kt = 0, i_stage = 0;
+    auto set_issue_tile = [&](int j) __attribute__((always_inline)) {
+        const int logical = xcd_remap((int)blockIdx.x + j * G, ntiles);
+        const int tn = logical % tiles_n, tmi = logical / tiles_n;
+        const int m0 = tmi * GBM, n0 = tn * BNOUT;
+#pragma unroll
+        for (int q = 0; q < A_IT; ++q) {
+            const int r = (q * 8 + wave) * 8 + srow;
+            const int chunk = pchunk ^ ((r >> 1) & 7);
+            const int m = m0 + r;
+            a_ptr[q] = (m < p.M) ? p.A + (size_t)m * p.lda + chunk * 8 : nullptr;
+        }
+#pragma unroll
+        for (int q = 0; q < B_IT; ++q) {
+            const int r = (q * 8 + wave) * 8 + srow;
+            const int chunk = pchunk ^ ((r >> 1) & 7);
+            int wrow;
+            if (GEGLU) wrow = (r < BN / 2) ? (n0 + r) : ((p.N >> 1) + n0 + (r - BN / 2));
+            else wrow = n0 + r;
+            b_ptr[q] = p.W + (size_t)wrow * p.K + chunk * 8;
+        }
+    };
+    auto issue_next = [&]() __attribute__((always_inline)) {
+        const int k0 = i_kt * GBK;
+        const unsigned sa = lds_base + i_stage * STAGE;
+        const unsigned sb = sa + A_BYTES;
+#pragma unroll
+        for (int q = 0; q < A_IT; ++q) glds16(a_ptr[q] ? a_ptr[q] + k0 : zero_ptr, sa + (q * 8 + wave) * 1024);
+#pragma unroll
+        for (int q = 0; q < B_IT; ++q) glds16(b_ptr[q] + k0, sb + (q * 8 + wave) * 1024);
+        if (++i_stage >= GSTAGES) i_stage = 0;
+        if (++i_kt >= nk) {
+            i_kt = 0;
+            ++i_tile;
+            if (i_tile < nj) set_issue_tile(i_tile);
+        }
+    };
+
+    f32x16_t acc[2][NB];
+    auto zero_acc = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < NB; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    };
+    zero_acc();
+
+    set_issue_tile(0);
+    issue_next();
+    if (GSTAGES >= 3 && total > 1) issue_next();
+    if (GSTAGES == 4 && total > 2) issue_next();
+
+    const bool out_f32 = (p.flags & DC_GEMM_OUT_F32) != 0;
+    int c_tile = 0, c_kt = 0, stage = 0;
+    for (int g = 0; g < total; ++g) {
+        // tile g has landed once at most the (GSTAGES-2) younger in-flight tiles' DMAs remain outstanding
+        const int younger = total - 1 - g;
+        if (GSTAGES == 4 && younger >= 2) wait_vmcnt<2 * LOADS>();
+        else if (GSTAGES >= 3 && younger >= 1) wait_vmcnt<LOADS>();
+        else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (g + GSTAGES - 1 < total) issue_next();
+        const char* sa = smem + stage * STAGE;
+        const char* sb = sa + A_BYTES;
+#pragma unroll
+        for (int kk = 0; kk < GBK / 16; ++kk) {
+            bf16x8_t xf[2], wf[NB];
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb)
+                xf[mb] = *reinterpret_cast<const bf16x8_t*>(sa + lds_off2(wm * 64 + mb * 32 + fr, kk * 2 + fh));
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) {
+                int brow;
+                if (GEGLU) brow = (nb < NBX ? 0 : BN / 2) + wn * (BN / 4) + (nb % NBX) * 32;
+                else brow = wn * (32 * NB) + nb * 32;
+                wf[nb] = *reinterpret_cast<const bf16x8_t*>(sb + lds_off2(brow + fr, kk * 2 + fh));
+            }
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb)
+                    acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[nb], xf[mb], acc[mb][nb], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
+        }
+        if (++stage >= GSTAGES) stage = 0;
+        if (++c_kt >= nk) {
+            // ---- epilogue of output tile c_tile, straight from registers
+            c_kt = 0;
+            const int logical = xcd_remap((int)blockIdx.x + c_tile * G, ntiles);
+            ++c_tile;
+            const int tn = logical % tiles_n, tmi = logical / tiles_n;
+            const int m0 = tmi * GBM, n0 = tn * BNOUT;
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb) {
+                const int m = m0 + wm * 64 + mb * 32 + fr;
+                const float* rv = p.rowvec ? p.rowvec + (size_t)((m < p.M ? m : 0) / p.rows_per_vec) * p.rowvec_ld : nullptr;
+#pragma unroll
+                for (int nb = 0; nb < NBX; ++nb)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int n = n0 + wn * WCOLS + nb * 32 + 8 * q + 4 * fh;
+                        if (m >= p.M || n >= n_out) continue;
+                        float4 v = make_float4(acc[mb][nb][4 * q], acc[mb][nb][4 * q + 1], acc[mb][nb][4 * q + 2],
+                                               acc[mb][nb][4 * q + 3]);
+                        if (p.bias) {
+                            const float4 bv = *reinterpret_cast<const float4*>(p.bias + n);
+                            v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+                        }
+                        if constexpr (GEGLU) {
+                            float4 gt = make_float4(acc[mb][nb + NBX][4 * q], acc[mb][nb + NBX][4 * q + 1],
+                                                    acc[mb][nb + NBX][4 * q + 2], acc[mb][nb + NBX][4 * q + 3]);
+                            if (p.bias) {
+                                const float4 bg = *reinterpret_cast<const float4*>(p.bias + (p.N >> 1) + n);
+                                gt.x += bg.x; gt.y += bg.y; gt.z += bg.z; gt.w += bg.w;
+                            }
+                            v.x *= gelu_erf_f(gt.x); v.y *= gelu_erf_f(gt.y); v.z *= gelu_erf_f(gt.z); v.w *= gelu_erf_f(gt.w);
+                        }
+                        if (rv) {
+                            const float4 r4 = *reinterpret_cast<const float4*>(rv + n);
+                            v.x += r4.x; v.y += r4.y; v.z += r4.z; v.w += r4.w;
+                        }
+                        v.x *= p.alpha; v.y *= p.alpha; v.z *= p.alpha; v.w *= p.alpha;
+                        if (out_f32) {
+                            *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.C) + (size_t)m * p.ldc + n) = v;
+                        } else {
+                            uint2 pk;
+                            pk.x = pack_bf2(v.x, v.y);
+                            pk.y = pack_bf2(v.z, v.w);
+                            if (p.residual) {
+                                const uint2 rr = *reinterpret_cast<const uint2*>(p.residual + (size_t)m * p.ldr + n);
+                                pk.x = pack_bf2(__uint_as_float(pk.x << 16) + __uint_as_float(rr.x << 16),
+                                                __uint_as_float(pk.x & 0xffff0000u) + __uint_as_float(rr.x & 0xffff0000u));
+                                pk.y = pack_bf2(__uint_as_float(pk.y << 16) + __uint_as_float(rr.y << 16),
+                                                __uint_as_float(pk.y & 0xffff0000u) + __uint_as_float(rr.y & 0xffff0000u));
+                            }
+                            *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.C) + (size_t)m * p.ldc + n) = pk;
+                        }
+                    }
+            }
+            zero_acc();
+        }
+    }
+}
+
+template <int BN, bool GEGLU>
+int launch_persist(const DcGemmParams& p, hipStream_t stream, int grid) {
+    // ring depth by LDS budget (160 KB): 64-wide 4 x 40 KB, 128-wide 3 x 48 KB, 256/320-wide 2 x 64/72 KB
+    constexpr int ST = (BN == 64) ? 4 : (BN == 128 ? 3 : 2);
+    constexpr size_t lds = (size_t)ST * (GBM * GBK * 2 + BN * GBK * 2);
+    static bool configured = false;
+    if (!configured) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_persist_kernel<BN, GEGLU, ST>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+        configured = true;
+    }
+    hipLaunchKernelGGL((gemm_persist_kernel<BN, GEGLU, ST>), dim3(grid), dim3(GNT), lds, stream, p);
+    DC_CHECK_LAUNCH();
+    return 0;
+}
+
 template <int BN, bool GEGLU, int MODE, int GSTAGES>
 int launch_glds(const DcGemmParams& p, hipStream_t stream) {
     constexpr int BNOUT = GEGLU ? BN / 2 : BN;
@@ -327,6 +540,11 @@ int launch_glds_mode(const DcGemmParams& p, hipStream_t stream) {
     return launch_glds<BN, false, 2, GSTAGES>(p, stream);
 }
 
+inline int persist_max_k() {
+    static const int v = [] { const char* e = getenv("DC_GEMM_PERSIST_MAXK"); return e ? atoi(e) : 1280; }();
+    return v;
+}
+
 // fraction of the chip's workgroup slots a grid of `wgs` one-per-CU workgroups keeps busy
 inline float wave_eff(int wgs) { return (float)wgs / (float)(((wgs + 255) / 256) * 256); }
 
@@ -338,8 +556,29 @@ int dc_gemm_conv_glds_try(const DcGemmParams& p, hipStream_t stream) {
     const int n_out = geglu ? p.N / 2 : p.N;
     const int tiles_m = (p.M + GBM - 1) / GBM;
     static const int force = [] { const char* e = getenv("DC_GEMM_TILE"); return e ? atoi(e) : 0; }();
+    static const int persist = [] { const char* e = getenv("DC_GEMM_PERSIST"); return e ? atoi(e) : 1; }();
+    if (geglu && p.mode != 0) return DC_ERR_ARG;
+    if (persist && force == 0 && p.mode == 0 && p.K <= persist_max_k()) {
+        // one workgroup per CU; needs at least 2 output tiles per workgroup to have anything to overlap
+        static const int wide = [] { const char* e = getenv("DC_GEMM_PERSIST_WIDE"); return e ? atoi(e) : 1; }();
+        if (geglu) {
+            // each workgroup re-streams its A panel once per N tile: the wider tile halves that traffic
+            if (wide && n_out % 128 == 0 && tiles_m * (n_out / 128) >= 512) return launch_persist<256, true>(p, stream, 256);
+            const int nt = tiles_m * (n_out / 64);
+            if (nt >= 512) return launch_persist<128, true>(p, stream, 256);
+        } else {
+            // N = 320*k: one 320-wide tile per A panel -> the activation rows cross the CU's load path once
+            // (concurrent N tiles all stream the panel at HBM rate; only in-CU reuse is free)
+            if (wide && p.N % 320 == 0 && p.n_pad >= p.N && tiles_m * (p.N / 320) >= 512)
+                return launch_persist<320, false>(p, stream, 256);
+            const int t128n = (p.N + 127) / 128;
+            const float waste = (float)(t128n * 128) / (float)p.N;
+            if (waste <= 1.15f && tiles_m * t128n >= 512) return launch_persist<128, false>(p, stream, 256);
+            const int t64n = (p.N + 63) / 64;
+            if (waste > 1.15f && tiles_m * t64n >= 512) return launch_persist<64, false>(p, stream, 256);
+        }
+    }
     if (geglu) {
-        if (p.mode != 0) return DC_ERR_ARG;
         const int w256 = (n_out % 128 == 0 && p.n_pad >= p.N) ? tiles_m * (n_out / 128) : 0;
         const int w128 = tiles_m * (n_out / 64);
         if ((force == 256 || (force == 0 && w256 >= 512 && wave_eff(w256) > 0.8f)) && w256 > 0)

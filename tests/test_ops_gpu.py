@@ -356,3 +356,36 @@ def test_tconv3_320_tile(ops):
     out = torch.empty_like(rows)
     ops.gemm(rows, pw, out, tconv=dict(T=T, HW=HW))
     assert rel_l2(out, ref.permute(0, 2, 3, 4, 1).reshape(-1, Cc)) < 4e-3
+
+
+# ---- persistent cross-tile pipelined GEMM (mode 0, >= 512 output tiles, K <= 1280) --------------------------
+@pytest.mark.parametrize("M,N,K", [(65536 + 50, 512, 320), (65536 + 50, 320, 320), (140000, 640, 640), (70000, 448, 64)])
+def test_gemm_persistent(ops, M, N, K):
+    test_gemm_plain_large(ops, M, N, K)
+
+
+def test_gemm_geglu_persistent(ops):
+    M, dim, inner = 65536 + 21, 320, 640
+    x = bf(rnd(M, dim, seed=1)); w = rnd(2 * inner, dim, seed=2, scale=dim ** -0.5); b = rnd(2 * inner, seed=3, scale=0.1)
+    pw = ops.PackedWeight.linear(w, b, DEV)
+    out = torch.empty(M, inner, dtype=torch.bfloat16, device=DEV)
+    ops.gemm(x.to(DEV), pw, out, geglu=True)
+    h = x.float() @ bf(w).float().t() + b
+    val, gate = h.chunk(2, dim=-1)
+    assert rel_l2(out, val * F.gelu(gate)) < 4e-3
+
+
+@pytest.mark.parametrize("M,N,K", [(140000, 320, 320), (140000, 640, 640), (135000, 960, 128)])
+def test_gemm_persistent_320(ops, M, N, K):
+    test_gemm_plain_large(ops, M, N, K)
+
+
+def test_gemm_geglu_persistent_256(ops):
+    M, dim, inner = 131072 + 21, 128, 512
+    x = bf(rnd(M, dim, seed=1)); w = rnd(2 * inner, dim, seed=2, scale=dim ** -0.5); b = rnd(2 * inner, seed=3, scale=0.1)
+    pw = ops.PackedWeight.linear(w, b, DEV)
+    out = torch.empty(M, inner, dtype=torch.bfloat16, device=DEV)
+    ops.gemm(x.to(DEV), pw, out, geglu=True)
+    h = x.float() @ bf(w).float().t() + b
+    val, gate = h.chunk(2, dim=-1)
+    assert rel_l2(out, val * F.gelu(gate)) < 4e-3
