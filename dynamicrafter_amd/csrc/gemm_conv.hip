@@ -8,7 +8,7 @@
 //                               (reference: openaimodel3d.py:68,96,103,151-180; ae_modules.py:96-106,117-126)
 //   mode 2  temporal conv 3x1x1 zero-padded in time          (reference: openaimodel3d.py:255-266)
 // Activations are channels-last rows [rows, C] (row = ((b*T + t)*H + y)*W + x), weights are [N][K] with
-// K = taps*Cin ordered (tap, ci), i.e. a 3x3 weight is stored [Cout][kh][kw][Cin].
+// K = taps*Cin ordered (64-channel slice, tap, channel), i.e. a 3x3 weight is stored [Cout][Cin/64][kh*kw][64].
 //
 // Tiling: 128 x BN x 64 per workgroup, 4 waves as 2(M) x 2(N), v_mfma_f32_32x32x16_bf16 with the operands swapped
 // (A-operand = weight fragment, B-operand = activation fragment) so that a lane ends up holding 4 consecutive
@@ -119,8 +119,11 @@ __global__ __launch_bounds__(NTHREADS) void gemm_conv_kernel(const DcGemmParams 
                 a_reg[i] = *reinterpret_cast<const u32x4_t*>(src);
             }
         } else if (MODE == 1) {
-            const int tap = k0 / p.Cin;
-            const int ci0 = k0 - tap * p.Cin;
+            // K is ordered (64-channel slice, tap, channel): the 9 taps of one slice are consecutive K tiles, so
+            // taps 2..9 re-read (shifted) rows that the first tap just pulled into L2
+            const int cs = kt / 9;
+            const int tap = kt - cs * 9;
+            const int ci0 = cs * 64;
             const int dy = tap / 3, dx = tap - dy * 3;
             const int eh = p.IH << p.ups, ew = p.IW << p.ups;
 #pragma unroll
@@ -132,8 +135,9 @@ __global__ __launch_bounds__(NTHREADS) void gemm_conv_kernel(const DcGemmParams 
                 a_reg[i] = *reinterpret_cast<const u32x4_t*>(src);
             }
         } else {
-            const int tap = k0 / p.Cin;
-            const int ci0 = k0 - tap * p.Cin;
+            const int cs = kt / 3;
+            const int tap = kt - cs * 3;
+            const int ci0 = cs * 64;
             const long long shift = (long long)(tap - 1) * p.HW * p.lda + ci0;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {

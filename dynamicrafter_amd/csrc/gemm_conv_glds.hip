@@ -140,8 +140,11 @@ __global__ __launch_bounds__(GNT) void gemm_conv_glds_kernel(const DcGemmParams 
                 glds16(src, sa + (j * 8 + wave) * 1024);
             }
         } else if (MODE == 1) {
-            const int tap = k0 / p.Cin;
-            const int ci0 = k0 - tap * p.Cin;
+            // K is ordered (64-channel slice, tap, channel): the 9 taps of one slice are consecutive K tiles, so
+            // taps 2..9 re-read (shifted) rows that the first tap just pulled into L2
+            const int cs = kt / 9;
+            const int tap = kt - cs * 9;
+            const int ci0 = cs * 64;
             const int dy = tap / 3, dx = tap - dy * 3;
             const int eh = p.IH << p.ups, ew = p.IW << p.ups;
 #pragma unroll
@@ -153,8 +156,9 @@ __global__ __launch_bounds__(GNT) void gemm_conv_glds_kernel(const DcGemmParams 
                 glds16(src, sa + (j * 8 + wave) * 1024);
             }
         } else {
-            const int tap = k0 / p.Cin;
-            const int ci0 = k0 - tap * p.Cin;
+            const int cs = kt / 3;
+            const int tap = kt - cs * 3;
+            const int ci0 = cs * 64;
             const long long shift = (long long)(tap - 1) * p.HW * p.lda + ci0;
 #pragma unroll
             for (int j = 0; j < A_IT; ++j) {

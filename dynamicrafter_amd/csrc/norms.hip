@@ -17,7 +17,7 @@ struct GnGeom { int chunks; int rows_per_chunk; };
 __host__ __device__ inline GnGeom gn_geom(int n_inst, int rows_per_inst) {
     int chunks = (2048 + n_inst - 1) / n_inst;
     int rpc = (rows_per_inst + chunks - 1) / chunks;
-    if (rpc < 32) rpc = 32;
+    if (rpc < 64) rpc = 64;
     GnGeom g;
     g.rows_per_chunk = rpc;
     g.chunks = (rows_per_inst + rpc - 1) / rpc;
@@ -38,7 +38,21 @@ __global__ void gn_partial_kernel(const bf16_t* __restrict__ x, int ldx, int C, 
 #pragma unroll
     for (int e = 0; e < 8; ++e) { s[e] = 0.f; ss[e] = 0.f; }
     const bf16_t* base = x + (size_t)inst * rows_per_inst * ldx + v * 8;
-    for (int r = r_begin + ro; r < r_end; r += rpp) {
+    int r = r_begin + ro;
+    // four independent 16-byte loads in flight per lane (HBM latency, not issue rate, bounds this pass)
+    for (; r + 3 * rpp < r_end; r += 4 * rpp) {
+        uint4 raw[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) raw[u] = *reinterpret_cast<const uint4*>(base + (size_t)(r + u * rpp) * ldx);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            float f[8];
+            unpack_bf8(raw[u], f);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { s[e] += f[e]; ss[e] += f[e] * f[e]; }
+        }
+    }
+    for (; r < r_end; r += rpp) {
         const uint4 raw = *reinterpret_cast<const uint4*>(base + (size_t)r * ldx);
         float f[8];
         unpack_bf8(raw, f);
@@ -115,7 +129,25 @@ __global__ void gn_apply_kernel(const bf16_t* __restrict__ x, int ldx, bf16_t* _
     }
     const bf16_t* xb = x + (size_t)inst * rows_per_inst * ldx + v * 8;
     bf16_t* yb = y + (size_t)inst * rows_per_inst * ldy + v * 8;
-    for (int r = r_begin + ro; r < r_end; r += rpp) {
+    int r = r_begin + ro;
+    for (; r + 3 * rpp < r_end; r += 4 * rpp) {
+        uint4 raw[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) raw[u] = *reinterpret_cast<const uint4*>(xb + (size_t)(r + u * rpp) * ldx);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            float f[8];
+            unpack_bf8(raw[u], f);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float t = f[e] * sc[e] + sh[e];
+                if (silu) t = silu_f(t);
+                f[e] = t;
+            }
+            *reinterpret_cast<uint4*>(yb + (size_t)(r + u * rpp) * ldy) = pack_bf8(f);
+        }
+    }
+    for (; r < r_end; r += rpp) {
         const uint4 raw = *reinterpret_cast<const uint4*>(xb + (size_t)r * ldx);
         float f[8];
         unpack_bf8(raw, f);
@@ -138,41 +170,52 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const bf16_t* __restrict
     const int wave = threadIdx.x >> 6;
     const int vecs = C >> 3;
     const float invC = 1.0f / (float)C;
-    for (int row = blockIdx.x * 4 + wave; row < rows; row += gridDim.x * 4) {
-        float f[MAXV][8];
-        float s = 0.f;
+    for (int row0 = (blockIdx.x * 4 + wave) * 2; row0 < rows; row0 += gridDim.x * 8) {
+        // two rows per wave in flight (independent load chains)
+        float f[2][MAXV][8];
+        float s[2] = {0.f, 0.f};
 #pragma unroll
-        for (int j = 0; j < MAXV; ++j) {
-            const int v = lane + 64 * j;
-            if (v < vecs) {
-                const uint4 raw = *reinterpret_cast<const uint4*>(x + (size_t)row * ldx + v * 8);
-                unpack_bf8(raw, f[j]);
+        for (int u = 0; u < 2; ++u) {
+            const int row = row0 + u < rows ? row0 + u : rows - 1;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) s += f[j][e];
-            }
-        }
-        const float mean = wave_sum(s) * invC;
-        float q = 0.f;
+            for (int j = 0; j < MAXV; ++j) {
+                const int v = lane + 64 * j;
+                if (v < vecs) {
+                    const uint4 raw = *reinterpret_cast<const uint4*>(x + (size_t)row * ldx + v * 8);
+                    unpack_bf8(raw, f[u][j]);
 #pragma unroll
-        for (int j = 0; j < MAXV; ++j) {
-            const int v = lane + 64 * j;
-            if (v < vecs) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) { const float d = f[j][e] - mean; q += d * d; }
-            }
-        }
-        const float rstd = rsqrtf(wave_sum(q) * invC + eps);
-#pragma unroll
-        for (int j = 0; j < MAXV; ++j) {
-            const int v = lane + 64 * j;
-            if (v < vecs) {
-                float o[8];
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const int c = v * 8 + e;
-                    o[e] = (f[j][e] - mean) * rstd * gamma[c] + beta[c];
+                    for (int e = 0; e < 8; ++e) s[u] += f[u][j][e];
                 }
-                *reinterpret_cast<uint4*>(y + (size_t)row * ldy + v * 8) = pack_bf8(o);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int row = row0 + u;
+            const float mean = wave_sum(s[u]) * invC;
+            float q = 0.f;
+#pragma unroll
+            for (int j = 0; j < MAXV; ++j) {
+                const int v = lane + 64 * j;
+                if (v < vecs) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { const float d = f[u][j][e] - mean; q += d * d; }
+                }
+            }
+            const float rstd = rsqrtf(wave_sum(q) * invC + eps);
+            if (row < rows) {
+#pragma unroll
+                for (int j = 0; j < MAXV; ++j) {
+                    const int v = lane + 64 * j;
+                    if (v < vecs) {
+                        float o[8];
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            const int c = v * 8 + e;
+                            o[e] = (f[u][j][e] - mean) * rstd * gamma[c] + beta[c];
+                        }
+                        *reinterpret_cast<uint4*>(y + (size_t)row * ldy + v * 8) = pack_bf8(o);
+                    }
+                }
             }
         }
     }
@@ -220,7 +263,7 @@ extern "C" int dc_layernorm(const uint16_t* x, int ldx, uint16_t* y, int ldy, co
     hipStream_t stream = (hipStream_t)stream_;
     if (!x || !y || !gamma || !beta) return DC_ERR_ARG;
     if (C % 8 != 0 || C > 2048 || ldx % 8 != 0 || ldy % 8 != 0 || rows <= 0) return DC_ERR_SHAPE;
-    int grid = (rows + 3) / 4;
+    int grid = (rows + 7) / 8;
     if (grid > 8192) grid = 8192;
     const int vecs = C / 8;
     if (vecs <= 64)

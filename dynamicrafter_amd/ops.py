@@ -87,8 +87,9 @@ def _rows(t, name="tensor", dtype=_BF16):
 
 
 class PackedWeight:
-    """Device copy of a Linear / conv weight in the layout dc_gemm_conv consumes: bf16 [n_pad][K], K ordered
-    (tap, ci), rows zero-padded to a multiple of 128. Derived from the nn.Parameter, never serialised."""
+    """Device copy of a Linear / conv weight in the layout dc_gemm_conv consumes: bf16 [n_pad][K]; conv K is
+    ordered (64-channel slice, tap, channel); rows zero-padded to a multiple of 128. Derived from the
+    nn.Parameter, never serialised."""
 
     __slots__ = ("w", "bias", "N", "K", "n_pad", "Cin", "taps", "k_real")
 
@@ -131,7 +132,8 @@ class PackedWeight:
         cip = (ci + 63) // 64 * 64
         if cip != ci:
             w = torch.nn.functional.pad(w, (0, cip - ci))
-        w = w.reshape(co, 9 * cip)
+        # K order = (64-channel slice, tap, channel-in-slice): the kernel walks all 9 taps of a slice back to back
+        w = w.reshape(co, 9, cip // 64, 64).permute(0, 2, 1, 3).reshape(co, 9 * cip)
         if co % n_align != 0:
             npad = (co + n_align - 1) // n_align * n_align
             w = torch.nn.functional.pad(w, (0, 0, 0, npad - co))
@@ -145,7 +147,8 @@ class PackedWeight:
     def tconv3(weight, bias, device):
         """nn.Conv3d (3,1,1) weight [Cout, Cin, 3, 1, 1] -> [Cout][kt][Cin]."""
         co, ci = weight.shape[0], weight.shape[1]
-        w = weight.detach().reshape(co, ci, 3).permute(0, 2, 1).reshape(co, 3 * ci)
+        assert ci % 64 == 0, "temporal conv width must be a multiple of 64"
+        w = weight.detach().reshape(co, ci // 64, 64, 3).permute(0, 1, 3, 2).reshape(co, 3 * ci)   # (slice, tap, channel)
         return PackedWeight._finish(w, bias, device, ci, 3)
 
 

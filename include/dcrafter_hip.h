@@ -13,8 +13,9 @@
  *     passed as void*), so every call is hipGraph-capturable.
  *   - device pointers only. bf16 = raw uint16 bits. Activations are channels-last rows: [rows, C] with
  *     row = ((b*T + t)*H + y)*W + x and `ld*` the row stride in elements.
- *   - weights are repacked once by the host: Linear [N][K] as in torch; conv3x3 [Cout][kh][kw][Cin];
- *     temporal conv [Cout][kt][Cin]; N zero-padded to a multiple of 128 rows; biases/affine params fp32.
+ *   - weights are repacked once by the host: Linear [N][K] as in torch; conv3x3 [Cout][Cin/64][kh*kw][64];
+ *     temporal conv [Cout][Cin/64][kt][64] (K = 64-channel slice, tap, channel); N zero-padded to a multiple of
+ *     128 rows; biases/affine params fp32.
  */
 #ifndef DCRAFTER_HIP_H
 #define DCRAFTER_HIP_H
