@@ -239,9 +239,14 @@ def main():
     if rank == 0:
         step_tf = STEP_TFLOP[res]
         ach = step_tf / (ms_per_step / 1e3)
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", f"r01_hbm_traffic_step{res}.json")
+        if os.path.exists(tpath):      # HBM bytes per step from rocprofv3 PMC passes (cannot be read live in-process)
+            traffic = json.load(open(tpath)).get("hbm_bytes_per_step")
         roof = {"bound": "mfma", "kernel": "denoising step (hipGraph: 2 batched UNet forwards + DDIM update)",
                 "achieved": round(ach, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(ach / MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                "frac": round(ach / MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
+                "traffic_source": "profiles/" + os.path.basename(tpath) if traffic else None,
                 "algorithmic_tflop_per_launch": step_tf}
         if not args.no_trace:
             log("event-traced eager step")
