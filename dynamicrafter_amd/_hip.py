@@ -12,6 +12,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libdcrafter_hip.so")
 
 DC_GEMM_OUT_F32 = 1
 DC_GEMM_GEGLU = 2
+DC_GEMM_GELU = 4
 
 
 class DcGemmParams(C.Structure):

@@ -279,6 +279,7 @@ __global__ __launch_bounds__(GNT) void gemm_conv_glds_kernel(const DcGemmParams 
                 }
                 v.x *= gelu_erf_f(g.x); v.y *= gelu_erf_f(g.y); v.z *= gelu_erf_f(g.z); v.w *= gelu_erf_f(g.w);
             }
+            if (p.flags & DC_GEMM_GELU) { v.x = gelu_erf_f(v.x); v.y = gelu_erf_f(v.y); v.z = gelu_erf_f(v.z); v.w = gelu_erf_f(v.w); }
             if (p.rowvec) {
                 const float4 rv = *reinterpret_cast<const float4*>(p.rowvec + (size_t)(m / p.rows_per_vec) * p.rowvec_ld + n);
                 v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
@@ -474,6 +475,7 @@ __global__ __launch_bounds__(GNT) void gemm_persist_kernel(const DcGemmParams p)
                             }
                             v.x *= gelu_erf_f(gt.x); v.y *= gelu_erf_f(gt.y); v.z *= gelu_erf_f(gt.z); v.w *= gelu_erf_f(gt.w);
                         }
+                        if (p.flags & DC_GEMM_GELU) { v.x = gelu_erf_f(v.x); v.y = gelu_erf_f(v.y); v.z = gelu_erf_f(v.z); v.w = gelu_erf_f(v.w); }
                         if (rv) {
                             const float4 r4 = *reinterpret_cast<const float4*>(rv + n);
                             v.x += r4.x; v.y += r4.y; v.z += r4.z; v.w += r4.w;

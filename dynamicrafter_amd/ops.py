@@ -152,7 +152,7 @@ class PackedWeight:
         return PackedWeight._finish(w, bias, device, ci, 3)
 
 
-def gemm(a, pw, out, *, M=None, residual=None, rowvec=None, rows_per_vec=1, geglu=False, alpha=1.0,
+def gemm(a, pw, out, *, M=None, residual=None, rowvec=None, rows_per_vec=1, geglu=False, gelu=False, alpha=1.0,
          conv=None, tconv=None):
     """out[M, N] = epilogue(gather(a) @ pw.w[:N].T). `out` dtype bf16 or float32 selects the output type.
 
@@ -175,7 +175,8 @@ def gemm(a, pw, out, *, M=None, residual=None, rowvec=None, rows_per_vec=1, gegl
     p.M = out.shape[0] if M is None else M
     p.N, p.K, p.n_pad = pw.N, pw.K, pw.n_pad
     p.Cin = pw.Cin
-    p.flags = (_hip.DC_GEMM_OUT_F32 if out_f32 else 0) | (_hip.DC_GEMM_GEGLU if geglu else 0)
+    p.flags = (_hip.DC_GEMM_OUT_F32 if out_f32 else 0) | (_hip.DC_GEMM_GEGLU if geglu else 0) | \
+        (_hip.DC_GEMM_GELU if gelu else 0)
     p.alpha = alpha
     if conv is not None:
         p.mode = 1

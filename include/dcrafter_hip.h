@@ -30,6 +30,7 @@ extern "C" {
 
 #define DC_GEMM_OUT_F32 1   /* C is float32 (no residual) */
 #define DC_GEMM_GEGLU   2   /* W = [value half ; gate half] (N = 2*Nout): C = (xW_v+b_v) * gelu_erf(xW_g+b_g) */
+#define DC_GEMM_GELU    4   /* C = gelu_erf(xW + b)  (Resampler FeedForward, lvdm/modules/encoders/resampler.py:27-34) */
 
 typedef struct DcGemmParams {
     const uint16_t* A;        /* activation rows (bf16) */

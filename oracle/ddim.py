@@ -141,7 +141,7 @@ def p_sample_ddim(sched: DDIMSchedule, x, index, e_cond, e_uncond=None, e_img=No
 
 @torch.no_grad()
 def ddim_sample(apply_model, sched: DDIMSchedule, x_T, cond, uncond=None, *, cfg_scale=1.0, guidance_rescale=0.0,
-                noises=None, temperature=1.0, **model_kwargs):
+                noises=None, temperature=1.0, uncond_img=None, cfg_img=None, **model_kwargs):
     """DDIMSampler.ddim_sampling ddim.py:134-203 with injected x_T / per-step noise.
     apply_model(x, t_long[b], cond_dict, **model_kwargs) -> model output."""
     img = x_T
@@ -152,10 +152,13 @@ def ddim_sample(apply_model, sched: DDIMSchedule, x_T, cond, uncond=None, *, cfg
         index = total - i - 1
         tl = torch.full((b,), int(step), dtype=torch.long)
         e_c = apply_model(img, tl, cond, **model_kwargs)
-        e_u = None
+        e_u = e_i = None
         if uncond is not None and cfg_scale != 1.0:
             e_u = apply_model(img, tl, uncond, **model_kwargs)
+            if uncond_img is not None:                    # 3-branch guidance (ddim_multiplecond.py:230-234)
+                e_i = apply_model(img, tl, uncond_img, **model_kwargs)
         nz = None if noises is None else noises[i]
-        img, _ = p_sample_ddim(sched, img, index, e_c, e_u, cfg_scale=cfg_scale, guidance_rescale=guidance_rescale,
+        img, _ = p_sample_ddim(sched, img, index, e_c, e_u, e_i, cfg_scale=cfg_scale,
+                               cfg_img=cfg_scale if cfg_img is None else cfg_img, guidance_rescale=guidance_rescale,
                                noise=nz, temperature=temperature)
     return img

@@ -316,7 +316,23 @@ def gen_first_stage():
     save("first_stage", video=vid, noise=torch.cat(noise, 0), z=z, rec=rec, scale_factor=np.array(model.scale_factor))
 
 
-GENS = dict(unet_tiny=gen_unet_tiny, unet_fullwidth=gen_unet_fullwidth, ae=gen_ae, schedules=gen_schedules,
+def gen_resampler():
+    """Reference Resampler: a narrow one and the released configuration (dim 1024, depth 4, 12 heads, 16 queries x 16
+    frames) with recipe weights."""
+    from lvdm.modules.encoders.resampler import Resampler
+    for tag, kw, n1 in (("tiny", dict(dim=128, depth=2, dim_head=64, heads=2, num_queries=4, embedding_dim=64,
+                                      output_dim=128, ff_mult=4, video_length=4), 9),
+                        ("full", dict(dim=1024, depth=4, dim_head=64, heads=12, num_queries=16, embedding_dim=1280,
+                                      output_dim=1024, ff_mult=4, video_length=16), 257)):
+        m = Resampler(**kw).eval()
+        shapes = load_recipe_weights(m, seed=14)
+        x = rnd(2 if tag == "tiny" else 1, n1, kw["embedding_dim"], seed=95)
+        with torch.no_grad():
+            y = m(x)
+        save(f"resampler_{tag}", x=x, y=y, param_names=np.array(sorted(shapes)), yaml_params=np.array(yaml.safe_dump(kw)))
+
+
+GENS = dict(resampler=gen_resampler, unet_tiny=gen_unet_tiny, unet_fullwidth=gen_unet_fullwidth, ae=gen_ae, schedules=gen_schedules,
             p_sample=gen_p_sample_known_answers, trajectory=gen_trajectory, first_stage=gen_first_stage)
 
 if __name__ == "__main__":

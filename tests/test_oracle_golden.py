@@ -166,3 +166,27 @@ def test_unet_fullwidth_matches_reference():
     sd = fill_state_dict(ounet.unet_param_shapes(cfg), seed=12)
     y = ounet.unet_forward(sd, cfg, T(g["x"]), T(g["timesteps"]), T(g["context"]), T(g["fs"]))
     assert maxrel(y, g["y"]) < 5e-5
+
+
+@pytest.mark.parametrize("tag", ["tiny", "full"])
+def test_resampler_matches_reference(tag):
+    from oracle import resampler as ores
+    g = load(f"resampler_{tag}")
+    kw = yaml.safe_load(str(g["yaml_params"]))
+    names = [str(s) for s in g["param_names"]]
+    # shapes follow from the constructor keywords; rebuild them the way the reference lays them out
+    dim, inner, ffd = kw["dim"], kw["heads"] * kw["dim_head"], int(kw["dim"] * kw["ff_mult"])
+    shapes = {"latents": (1, kw["num_queries"] * kw["video_length"], dim), "proj_in.weight": (dim, kw["embedding_dim"]),
+              "proj_in.bias": (dim,), "proj_out.weight": (kw["output_dim"], dim), "proj_out.bias": (kw["output_dim"],),
+              "norm_out.weight": (kw["output_dim"],), "norm_out.bias": (kw["output_dim"],)}
+    for i in range(kw["depth"]):
+        p = f"layers.{i}"
+        shapes.update({f"{p}.0.norm1.weight": (dim,), f"{p}.0.norm1.bias": (dim,), f"{p}.0.norm2.weight": (dim,),
+                       f"{p}.0.norm2.bias": (dim,), f"{p}.0.to_q.weight": (inner, dim),
+                       f"{p}.0.to_kv.weight": (2 * inner, dim), f"{p}.0.to_out.weight": (dim, inner),
+                       f"{p}.1.0.weight": (dim,), f"{p}.1.0.bias": (dim,), f"{p}.1.1.weight": (ffd, dim),
+                       f"{p}.1.3.weight": (dim, ffd)})
+    assert sorted(shapes) == names
+    sd = fill_state_dict(shapes, seed=14)
+    y = ores.resampler_forward(sd, T(g["x"]), kw["heads"], kw["depth"])
+    assert maxrel(y, g["y"]) < 2e-5
