@@ -11,6 +11,7 @@ Additions for the MI355X path (not in the reference): `apply_model_rows` evaluat
 hands the raw row output to the fused DDIM kernel; DDIMSampler uses it when present.
 """
 import logging
+import os
 from functools import partial
 
 import numpy as np
@@ -288,7 +289,12 @@ class LatentDiffusion(DDPM):
             if fs is None:
                 fs = torch.full((B,), net.default_fs, dtype=torch.int64, device=dev)
             fs_table = fs.to(device=dev, dtype=torch.int64).repeat(nb).contiguous()
-        return dict(nb=nb, ccs=ccs, ctx_all=ctx_all, Lc=Lc, fs_table=fs_table, shape=tuple(x_shape))
+        # branches that share the latent AND the concat conditioning have identical activations up to the first
+        # cross-attention: the UNet computes that prefix once (openaimodel3d.forward_rows shared_prefix)
+        same_cc = all((c is ccs[0]) or (c is not None and ccs[0] is not None and c.shape == ccs[0].shape
+                                         and bool(torch.equal(c, ccs[0]))) for c in ccs)
+        share = nb if (same_cc and nb > 1 and os.environ.get("DC_SHARED_PREFIX", "1") != "0") else 1
+        return dict(nb=nb, ccs=ccs, ctx_all=ctx_all, Lc=Lc, fs_table=fs_table, shape=tuple(x_shape), share=share)
 
     def apply_model_rows(self, x, prep, t_table, t_index=None):
         """All branches of `prep` on the same latent x as ONE batched UNet forward (kernel launches only; safe
@@ -304,7 +310,7 @@ class LatentDiffusion(DDPM):
             ops.pack_latent(x, cc, xr[k * M:(k + 1) * M], B=B, Cx=Cx, Cc=0 if cc is None else cc.shape[1], T=T, HW=H * W)
         Lc = prep["Lc"]
         return net.forward_rows(xr, t_table, prep["ctx_all"], B=nb * B, T=T, H=H, W=W, Lc=Lc, n_text=min(77, Lc),
-                                fs_table=prep["fs_table"], t_index=t_index)
+                                fs_table=prep["fs_table"], t_index=t_index, shared_prefix=prep.get("share", 1))
 
 
 class LatentVisualDiffusion(LatentDiffusion):

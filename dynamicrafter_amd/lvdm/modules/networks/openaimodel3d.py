@@ -405,14 +405,21 @@ class UNetModel(nn.Module):
         mid = ops.gemm(n, Wb["ff1"], A.get("ffmid", h.shape[0], Wb["ff1"].N // 2, device=h.device), geglu=True)
         return ops.gemm(mid, Wb["ff2"], h, residual=h)
 
-    def _spatial(self, W, x, g, heads, out_tag):
+    def _spatial_pre(self, W, x, g, heads):
+        """SpatialTransformer up to and including the self-attention residual: everything that does not see the
+        context (identical for all guidance branches of one latent)."""
         A = self._arena
         M, dev, Cc = x.shape[0], x.device, x.shape[1]
         n = self._gn(x, W["norm"], "gn", n_inst=g["F"], rpi=g["HW"], eps=1e-6, silu=False)
         h = ops.gemm(n, W["proj_in"], A.get("tr_h", M, Cc, device=dev))
         B_ = W["blk"]
-        h = self._attn_self_spatial(B_["attn1"], self._ln(h, B_["norm1"], "ln"), h, g, heads)
-        # dual cross-attention: shared q, text keys then image keys accumulated with the image scale
+        return self._attn_self_spatial(B_["attn1"], self._ln(h, B_["norm1"], "ln"), h, g, heads)
+
+    def _spatial_post(self, W, x, h, g, heads, out_tag):
+        """dual cross-attention (shared q; text keys, then image keys accumulated with the image scale), FF, proj_out."""
+        A = self._arena
+        M, dev, Cc = x.shape[0], x.device, x.shape[1]
+        B_ = W["blk"]
         n = self._ln(h, B_["norm2"], "ln")
         q = ops.gemm(n, B_["q2"], A.get("q2", M, Cc, device=dev))
         ctx = g["ctx"]                                   # rows [F * Lc, D], Lc = n_text + L_img
@@ -427,6 +434,9 @@ class UNetModel(nn.Module):
         h = ops.gemm(att, B_["out2"], h, residual=h)
         h = self._ff(B_, h)
         return ops.gemm(h, W["proj_out"], A.get(out_tag, M, Cc, device=dev), residual=x)
+
+    def _spatial(self, W, x, g, heads, out_tag):
+        return self._spatial_post(W, x, self._spatial_pre(W, x, g, heads), g, heads, out_tag)
 
     def _temporal(self, W, x, g, heads, out_tag):
         A = self._arena
@@ -467,7 +477,15 @@ class UNetModel(nn.Module):
         return h
 
     # ------------------------------------------------------------------ forward on rows
-    def forward_rows(self, xrows, t_table, ctx_rows, *, B, T, H, W, Lc, n_text=77, fs_table=None, t_index=None):
+    def _replicate(self, src, tag, nrep):
+        """rows [M, C] -> [nrep*M, C] (the guidance branches start from identical activations)"""
+        dst = self._arena.get(tag, nrep * src.shape[0], src.shape[1], device=src.device)
+        for k in range(nrep):
+            ops.copy2d(src, dst[k * src.shape[0]:(k + 1) * src.shape[0]])
+        return dst
+
+    def forward_rows(self, xrows, t_table, ctx_rows, *, B, T, H, W, Lc, n_text=77, fs_table=None, t_index=None,
+                     shared_prefix=1):
         """xrows: bf16 [B*T*H*W, 64] (latent+concat channels, zero padded); t_table int64 [*, B] (row selected by
         the device counter t_index, or row 0); ctx_rows bf16 [B*T*Lc, context_dim]; fs_table int64 [B].
         Returns fp32 rows [B*T*H*W, 4] (channels-last model output)."""
@@ -491,7 +509,33 @@ class UNetModel(nn.Module):
         down_path, middle, up_path = self._layout
         h = xrows
         skips = []
+        first = 0
+        nrep = shared_prefix
+        if nrep > 1 and len(down_path) > 1 and [k for k, _ in down_path[1]][:2] == ["res", "spatial"]:
+            # The `nrep` guidance branches share latent, c_concat, timestep and fs: everything before the first
+            # cross-attention (conv_in, init_attn, the first ResBlock, the first SpatialTransformer's self-attention)
+            # is computed ONCE on B/nrep clips and replicated; results are bit-identical to the full batch.
+            B1 = B // nrep
+            g1 = dict(g, B=B1, F=B1 * T)
+            h = self._run_block(down_path[0], Wt["in"][0], h[:B1 * T * H * W], g1, "in0")
+            if self.addition_attention:
+                h = self._temporal(Wt["init_attn"], h, g1, 8, "init_attn")
+            skips.append((self._replicate(h, "in0.rep", nrep), H, W))
+            blk, Wb = down_path[1], Wt["in"][1]
+            r = self._res(Wb[0], h, g1, "in1.0")
+            hh = self._spatial_pre(Wb[1], r, g1, blk[1][1]["heads"])
+            r_full = self._replicate(r, "in1.0.rep", nrep)
+            h_full = self._replicate(hh, "tr_h.rep", nrep)
+            h = self._spatial_post(Wb[1], r_full, h_full, g, blk[1][1]["heads"], "in1.1")
+            for j in range(2, len(blk)):
+                kind, a = blk[j]
+                assert kind == "temporal"
+                h = self._temporal(Wb[j], h, g, a["heads"], f"in1.{j}")
+            skips.append((h, H, W))
+            first = 2
         for i, blk in enumerate(down_path):
+            if i < first:
+                continue
             h = self._run_block(blk, Wt["in"][i], h, g, f"in{i}")
             if i == 0 and self.addition_attention:
                 h = self._temporal(Wt["init_attn"], h, g, 8, "init_attn")

@@ -292,3 +292,25 @@ def test_three_branch_cfg_fused_vs_oracle():
                                                noises=noises.to(DEV), cfg_img=2.0,
                                                unconditional_conditioning_img_nonetext=mk(ctx[2]))
     assert rel_l2(out2, ref) < 1e-1 and rel_l2(out2, out) < 5e-2
+
+
+def test_shared_prefix_is_bit_identical(monkeypatch):
+    """cond/uncond share latent + c_concat: computing the context-free prefix once must not change a single bit."""
+    from dynamicrafter_amd.lvdm.models.samplers.ddim import DDIMSampler
+    g = load("trajectory_512")
+    outs = []
+    for flag in ("1", "0"):
+        monkeypatch.setenv("DC_SHARED_PREFIX", flag)
+        model = _tiny_lvd("inference_512_v1.0.yaml")
+        cc = T(g["c_concat"])
+        cond = {"c_crossattn": [T(g["ctx"])], "c_concat": [cc]}
+        uc = {"c_crossattn": [T(g["uc_ctx"])], "c_concat": [cc]}
+        s = DDIMSampler(model)
+        x_T = T(g["x_T"])
+        samples, _ = s.sample(S=3, batch_size=1, shape=tuple(x_T.shape[1:]), conditioning=cond, verbose=False,
+                              unconditional_guidance_scale=7.5, unconditional_conditioning=uc, eta=1.0, x_T=x_T,
+                              fs=T(g["fs"]), timestep_spacing="uniform_trailing", guidance_rescale=0.7,
+                              noises=T(g["noises"])[:3])
+        assert s._last_run.prep["share"] == (2 if flag == "1" else 1)
+        outs.append(samples.clone())
+    assert torch.equal(outs[0], outs[1])
