@@ -29,7 +29,11 @@ constexpr int FA_KBYTES = FA_BKV * 128;
 constexpr int FA_VBYTES = FA_BKV * V_LD;
 constexpr int FA_STAGE = FA_KBYTES + FA_VBYTES;
 
-__global__ __launch_bounds__(256) void flash_attn_d64_kernel(
+// QB = 32-row query blocks per wave. QB = 2 reads every K / V fragment from LDS once for two query blocks: at QB = 1
+// the kernel moves 16 KB of LDS reads per wave per 16 MFMAs, i.e. ~256 B/clk/CU at two workgroups per CU — the LDS
+// bandwidth itself — so doubling the MFMAs per fragment is what lifts the bound.
+template <int QB>
+__global__ __launch_bounds__(256, 2) void flash_attn_d64_kernel(
     const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v, bf16_t* __restrict__ o,
     int ldq, int ldk, int ldv, int ldo, int heads, int Lq, int Lk, int64_t q_bstride, int64_t kv_bstride,
     float c /* scale*log2(e) */, int accumulate, float acc_scale, int q_tiles) {
@@ -49,13 +53,17 @@ __global__ __launch_bounds__(256) void flash_attn_d64_kernel(
     const bf16_t* vb = v + (size_t)b * kv_bstride * ldv + head * 64;
     bf16_t* ob = o + (size_t)b * q_bstride * ldo + head * 64;
 
-    // ---- Q fragments (B operand): lane (r, h) holds Q[i0 + r][16kk + 8h .. +7]
-    const int qrow = qt * FA_BQ + wave * 32 + fr;
-    const int qrow_c = qrow < Lq ? qrow : Lq - 1;
-    bf16x8_t qf[4];
+    // ---- Q fragments (B operand): lane (r, h) holds Q[row][16kk + 8h .. +7] for each of its QB query blocks
+    int qrow[QB];
+    bf16x8_t qf[QB][4];
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk)
-        qf[kk] = *reinterpret_cast<const bf16x8_t*>(qb + (size_t)qrow_c * ldq + kk * 16 + fh * 8);
+    for (int x = 0; x < QB; ++x) {
+        qrow[x] = qt * (FA_BQ * QB) + (wave * QB + x) * 32 + fr;
+        const int qc = qrow[x] < Lq ? qrow[x] : Lq - 1;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+            qf[x][kk] = *reinterpret_cast<const bf16x8_t*>(qb + (size_t)qc * ldq + kk * 16 + fh * 8);
+    }
 
     // ---- staging coordinates: 64 rows x 8 chunks per tensor, 2 rows per thread
     const int chunk = tid & 7, srow = tid >> 3;
@@ -82,12 +90,16 @@ __global__ __launch_bounds__(256) void flash_attn_d64_kernel(
         }
     };
 
-    f32x16_t oacc[2];
+    f32x16_t oacc[QB][2];
+    float m_run[QB], l_run[QB];
 #pragma unroll
-    for (int d = 0; d < 2; ++d)
+    for (int x = 0; x < QB; ++x) {
+        m_run[x] = -1e30f; l_run[x] = 0.f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) oacc[d][r] = 0.f;
-    float m_run = -1e30f, l_run = 0.f;
+        for (int d = 0; d < 2; ++d)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) oacc[x][d][r] = 0.f;
+    }
 
     const int nt = (Lk + FA_BKV - 1) / FA_BKV;
     load_tile(0);
@@ -105,69 +117,83 @@ __global__ __launch_bounds__(256) void flash_attn_d64_kernel(
         const char* sk = smem + buf * FA_STAGE;
         const char* sv = sk + FA_KBYTES;
 
-        // S^T[jb] = K[jb] Q^T
-        f32x16_t s[2];
+        // S^T[x][jb] = K[jb] Q[x]^T  — every K fragment is read once and used for all QB query blocks
+        f32x16_t s[QB][2];
 #pragma unroll
-        for (int jb = 0; jb < 2; ++jb) {
+        for (int x = 0; x < QB; ++x)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) s[jb][r] = 0.f;
+            for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s[x][jb][r] = 0.f;
+#pragma unroll
+        for (int jb = 0; jb < 2; ++jb)
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) {
                 const bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(sk + k_lds_off(jb * 32 + fr, kk * 2 + fh));
-                s[jb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[kk], s[jb], 0, 0, 0);
+#pragma unroll
+                for (int x = 0; x < QB; ++x)
+                    s[x][jb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[x][kk], s[x][jb], 0, 0, 0);
             }
-        }
         // mask keys beyond Lk (last tile only)
         if ((t + 1) * FA_BKV > Lk) {
+#pragma unroll
+            for (int x = 0; x < QB; ++x)
+#pragma unroll
+                for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int j = t * FA_BKV + jb * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+                        if (j >= Lk) s[x][jb][r] = -1e30f;
+                    }
+        }
+        // online softmax: this lane owns one query row per block; its partner (lane ^ 32) holds the other keys
+#pragma unroll
+        for (int x = 0; x < QB; ++x) {
+            float mx = fmaxf(fmaxf(s[x][0][0], s[x][0][1]), s[x][0][2]);
+#pragma unroll
+            for (int r = 3; r < 15; r += 2) mx = fmaxf(fmaxf(mx, s[x][0][r]), s[x][0][r + 1]);
+            mx = fmaxf(mx, s[x][0][15]);
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) mx = fmaxf(fmaxf(mx, s[x][1][r]), s[x][1][r + 1]);
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            // rescale only when some row's running max actually grew (alpha == 1 exactly otherwise: skipping is exact)
+            if (__any(mx > m_run[x])) {
+                const float m_new = fmaxf(m_run[x], mx);
+                const float alpha = __builtin_amdgcn_exp2f((m_run[x] - m_new) * c);
+                m_run[x] = m_new;
+                l_run[x] *= alpha;
+#pragma unroll
+                for (int d = 0; d < 2; ++d)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) oacc[x][d][r] *= alpha;
+            }
+            const float mc = m_run[x] * c;
+            float psum = 0.f;
 #pragma unroll
             for (int jb = 0; jb < 2; ++jb)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int j = t * FA_BKV + jb * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
-                    if (j >= Lk) s[jb][r] = -1e30f;
+                    const float p = __builtin_amdgcn_exp2f(fmaf(s[x][jb][r], c, -mc));
+                    s[x][jb][r] = p;
+                    psum += p;
                 }
+            l_run[x] += psum;
         }
-        // online softmax: this lane owns query row `fr`; its partner (lane ^ 32) holds the other keys
-        float mx = fmaxf(fmaxf(s[0][0], s[0][1]), s[0][2]);
-#pragma unroll
-        for (int r = 3; r < 15; r += 2) mx = fmaxf(fmaxf(mx, s[0][r]), s[0][r + 1]);
-        mx = fmaxf(mx, s[0][15]);
-#pragma unroll
-        for (int r = 0; r < 16; r += 2) mx = fmaxf(fmaxf(mx, s[1][r]), s[1][r + 1]);
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        // rescale only when some row's running max actually grew (alpha == 1 exactly otherwise: skipping is exact)
-        if (__any(mx > m_run)) {
-            const float m_new = fmaxf(m_run, mx);
-            const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
-            m_run = m_new;
-            l_run *= alpha;
-#pragma unroll
-            for (int d = 0; d < 2; ++d)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) oacc[d][r] *= alpha;
-        }
-        const float mc = m_run * c;
-        float psum = 0.f;
-#pragma unroll
-        for (int jb = 0; jb < 2; ++jb)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float p = __builtin_amdgcn_exp2f(fmaf(s[jb][r], c, -mc));
-                s[jb][r] = p;
-                psum += p;
-            }
-        l_run += psum;
 
-        // O^T[db] += V^T[db][keys] P^T[keys]
+        // O^T[x][db] += V^T[db][keys] P[x]^T[keys] — every V^T fragment is read once for all QB query blocks
 #pragma unroll
         for (int jb = 0; jb < 2; ++jb)
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
-                u32x4_t pw;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) pw[e] = pack_bf2(s[jb][8 * ks + 2 * e], s[jb][8 * ks + 2 * e + 1]);
-                const bf16x8_t pf = __builtin_bit_cast(bf16x8_t, pw);
                 const int jbase = jb * 32 + 16 * ks + 4 * fh;
+                bf16x8_t pf[QB];          // P fragments are packed right before use: S registers die here
+#pragma unroll
+                for (int x = 0; x < QB; ++x) {
+                    u32x4_t pw;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) pw[e] = pack_bf2(s[x][jb][8 * ks + 2 * e], s[x][jb][8 * ks + 2 * e + 1]);
+                    pf[x] = __builtin_bit_cast(bf16x8_t, pw);
+                }
 #pragma unroll
                 for (int db = 0; db < 2; ++db) {
                     const char* vp = sv + jbase * V_LD + db * 64 + tr_off;
@@ -176,37 +202,42 @@ __global__ __launch_bounds__(256) void flash_attn_d64_kernel(
                     bf16x8_t vf;
                     vf[0] = lo[0]; vf[1] = lo[1]; vf[2] = lo[2]; vf[3] = lo[3];
                     vf[4] = hi[0]; vf[5] = hi[1]; vf[6] = hi[2]; vf[7] = hi[3];
-                    oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, oacc[db], 0, 0, 0);
+#pragma unroll
+                    for (int x = 0; x < QB; ++x)
+                        oacc[x][db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[x], oacc[x][db], 0, 0, 0);
                 }
             }
         store_tile(buf ^ 1);
         __syncthreads();
     }
 
-    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
-    const float inv = 1.0f / l_tot;
-    if (qrow < Lq) {
-        bf16_t* orow = ob + (size_t)qrow * ldo;
 #pragma unroll
-        for (int db = 0; db < 2; ++db)
+    for (int x = 0; x < QB; ++x) {
+        const float l_tot = l_run[x] + __shfl_xor(l_run[x], 32, 64);
+        const float inv = 1.0f / l_tot;
+        if (qrow[x] < Lq) {
+            bf16_t* orow = ob + (size_t)qrow[x] * ldo;
 #pragma unroll
-            for (int qd = 0; qd < 4; ++qd) {
-                const int d = db * 32 + 8 * qd + 4 * fh;
-                float v0 = oacc[db][4 * qd + 0] * inv, v1 = oacc[db][4 * qd + 1] * inv;
-                float v2 = oacc[db][4 * qd + 2] * inv, v3 = oacc[db][4 * qd + 3] * inv;
-                uint2* dst = reinterpret_cast<uint2*>(orow + d);
-                if (accumulate) {
-                    const uint2 old = *dst;
-                    v0 = __uint_as_float(old.x << 16) + acc_scale * v0;
-                    v1 = __uint_as_float(old.x & 0xffff0000u) + acc_scale * v1;
-                    v2 = __uint_as_float(old.y << 16) + acc_scale * v2;
-                    v3 = __uint_as_float(old.y & 0xffff0000u) + acc_scale * v3;
+            for (int db = 0; db < 2; ++db)
+#pragma unroll
+                for (int qd = 0; qd < 4; ++qd) {
+                    const int d = db * 32 + 8 * qd + 4 * fh;
+                    float v0 = oacc[x][db][4 * qd + 0] * inv, v1 = oacc[x][db][4 * qd + 1] * inv;
+                    float v2 = oacc[x][db][4 * qd + 2] * inv, v3 = oacc[x][db][4 * qd + 3] * inv;
+                    uint2* dst = reinterpret_cast<uint2*>(orow + d);
+                    if (accumulate) {
+                        const uint2 old = *dst;
+                        v0 = __uint_as_float(old.x << 16) + acc_scale * v0;
+                        v1 = __uint_as_float(old.x & 0xffff0000u) + acc_scale * v1;
+                        v2 = __uint_as_float(old.y << 16) + acc_scale * v2;
+                        v3 = __uint_as_float(old.y & 0xffff0000u) + acc_scale * v3;
+                    }
+                    uint2 pk;
+                    pk.x = pack_bf2(v0, v1);
+                    pk.y = pack_bf2(v2, v3);
+                    *dst = pk;
                 }
-                uint2 pk;
-                pk.x = pack_bf2(v0, v1);
-                pk.y = pack_bf2(v2, v3);
-                *dst = pk;
-            }
+        }
     }
 }
 
@@ -312,12 +343,19 @@ extern "C" int dc_flash_attn_d64(const uint16_t* q, const uint16_t* k, const uin
     if (!q || !k || !v || !o) return DC_ERR_ARG;
     if (batch <= 0 || heads <= 0 || Lq <= 0 || Lk <= 0) return DC_ERR_SHAPE;
     if (ldq % 8 || ldk % 8 || ldv % 8 || ldo % 4) return DC_ERR_SHAPE;
-    const int q_tiles = (Lq + FA_BQ - 1) / FA_BQ;
+    const float c = scale * 1.4426950408889634f;
+    // two query blocks per wave (256 rows per workgroup) once there are enough rows and keys to pay for it
+    const bool wide = Lq >= 512 && Lk >= 256;
+    const int rows_wg = wide ? 2 * FA_BQ : FA_BQ;
+    const int q_tiles = (Lq + rows_wg - 1) / rows_wg;
     const long long nwg = (long long)q_tiles * heads * batch;
     if (nwg > 0x7fffffffLL) return DC_ERR_SHAPE;
-    const float c = scale * 1.4426950408889634f;
-    hipLaunchKernelGGL(flash_attn_d64_kernel, dim3((unsigned)nwg), dim3(256), 0, stream, q, k, v, o, ldq, ldk, ldv, ldo,
-                       heads, Lq, Lk, q_bstride, kv_bstride, c, accumulate, acc_scale, q_tiles);
+    if (wide)
+        hipLaunchKernelGGL(flash_attn_d64_kernel<2>, dim3((unsigned)nwg), dim3(256), 0, stream, q, k, v, o, ldq, ldk, ldv,
+                           ldo, heads, Lq, Lk, q_bstride, kv_bstride, c, accumulate, acc_scale, q_tiles);
+    else
+        hipLaunchKernelGGL(flash_attn_d64_kernel<1>, dim3((unsigned)nwg), dim3(256), 0, stream, q, k, v, o, ldq, ldk, ldv,
+                           ldo, heads, Lq, Lk, q_bstride, kv_bstride, c, accumulate, acc_scale, q_tiles);
     DC_CHECK_LAUNCH();
     return 0;
 }
