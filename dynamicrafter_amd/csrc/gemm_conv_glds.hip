@@ -14,6 +14,7 @@
 // lane-linear (base + lane*16), the swizzle is applied to the per-lane SOURCE address.
 #include "dc_common.h"
 #include "dcrafter_hip.h"
+#include <stdint.h>
 #include <stdlib.h>
 
 namespace {
@@ -129,47 +130,50 @@ __global__ __launch_bounds__(GNT) void gemm_conv_glds_kernel(const DcGemmParams 
 
     const int nk = p.K / GBK;
 
-    auto issue_tile = [&](int kt, int stage) __attribute__((always_inline)) {
+    // One quarter of a K tile's LDS-DMA: A instruction `part` and the B instructions j with j % 4 == part. The main
+    // loop issues one quarter ahead of each 16-wide K step instead of the whole tile in one burst: a burst of
+    // (4 + BN/64) x 8 KB per workgroup stalls the MFMA stream behind it (tools/ubench/gemm_core.hip: 256 x 320 tile,
+    // cache-resident operands, 1.39 -> 1.69 PFLOP/s-equivalent with spread issue and without s_setprio).
+    auto issue_part = [&](int kt, int stage, int part) __attribute__((always_inline)) {
         const int k0 = kt * GBK;
         const unsigned sa = lds_base + stage * STAGE;
         const unsigned sb = sa + A_BYTES;
-        if (MODE == 0) {
 #pragma unroll
-            for (int j = 0; j < A_IT; ++j) {
-                const bf16_t* src = (a_base[j] >= 0) ? a_ptr[j] + k0 : zero_ptr;
-                glds16(src, sa + (j * 8 + wave) * 1024);
-            }
-        } else if (MODE == 1) {
-            // K is ordered (64-channel slice, tap, channel): the 9 taps of one slice are consecutive K tiles, so
-            // taps 2..9 re-read (shifted) rows that the first tap just pulled into L2
-            const int cs = kt / 9;
-            const int tap = kt - cs * 9;
-            const int ci0 = cs * 64;
-            const int dy = tap / 3, dx = tap - dy * 3;
-            const int eh = p.IH << p.ups, ew = p.IW << p.ups;
-#pragma unroll
-            for (int j = 0; j < A_IT; ++j) {
+        for (int j = 0; j < A_IT; ++j) {
+            if (j != part) continue;
+            const bf16_t* src;
+            if (MODE == 0) {
+                src = (a_base[j] >= 0) ? a_ptr[j] + k0 : zero_ptr;
+            } else if (MODE == 1) {
+                // K is ordered (64-channel slice, tap, channel): the 9 taps of one slice are consecutive K tiles, so
+                // taps 2..9 re-read (shifted) rows that the first tap just pulled into L2
+                const int cs = kt / 9;
+                const int tap = kt - cs * 9;
+                const int ci0 = cs * 64;
+                const int dy = tap / 3, dx = tap - dy * 3;
+                const int eh = p.IH << p.ups, ew = p.IW << p.ups;
                 const int iy = a_y[j] + dy, ix = a_x[j] + dx;
                 const bool ok = (a_base[j] >= 0) & (iy >= 0) & (iy < eh) & (ix >= 0) & (ix < ew);
                 const int srcrow = a_base[j] + (iy >> p.ups) * p.IW + (ix >> p.ups);
-                const bf16_t* src = ok ? a_ptr[j] + (size_t)srcrow * p.lda + ci0 : zero_ptr;
-                glds16(src, sa + (j * 8 + wave) * 1024);
-            }
-        } else {
-            const int cs = kt / 3;
-            const int tap = kt - cs * 3;
-            const int ci0 = cs * 64;
-            const long long shift = (long long)(tap - 1) * p.HW * p.lda + ci0;
-#pragma unroll
-            for (int j = 0; j < A_IT; ++j) {
+                src = ok ? a_ptr[j] + (size_t)srcrow * p.lda + ci0 : zero_ptr;
+            } else {
+                const int cs = kt / 3;
+                const int tap = kt - cs * 3;
+                const int ci0 = cs * 64;
+                const long long shift = (long long)(tap - 1) * p.HW * p.lda + ci0;
                 const int tt = a_y[j] + tap - 1;
                 const bool ok = (a_base[j] >= 0) & (tt >= 0) & (tt < p.T);
-                const bf16_t* src = ok ? a_ptr[j] + shift : zero_ptr;
-                glds16(src, sa + (j * 8 + wave) * 1024);
+                src = ok ? a_ptr[j] + shift : zero_ptr;
             }
+            glds16(src, sa + (j * 8 + wave) * 1024);
         }
 #pragma unroll
-        for (int j = 0; j < B_IT; ++j) glds16(b_ptr[j] + k0, sb + (j * 8 + wave) * 1024);
+        for (int j = 0; j < B_IT; ++j)
+            if ((j & 3) == part) glds16(b_ptr[j] + k0, sb + (j * 8 + wave) * 1024);
+    };
+    auto issue_tile = [&](int kt, int stage) __attribute__((always_inline)) {
+#pragma unroll
+        for (int part = 0; part < 4; ++part) issue_part(kt, stage, part);
     };
 
     f32x16_t acc[2][NB];
@@ -190,14 +194,13 @@ __global__ __launch_bounds__(GNT) void gemm_conv_glds_kernel(const DcGemmParams 
         if (GSTAGES == 3 && kt + 1 < nk) wait_vmcnt<LOADS>(); else wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();        // everyone's share of tile kt is in LDS; everyone is done with tile kt-1
         asm volatile("" ::: "memory");
-        if (kt + GSTAGES - 1 < nk) {
-            int s2 = stage + GSTAGES - 1; if (s2 >= GSTAGES) s2 -= GSTAGES;
-            issue_tile(kt + GSTAGES - 1, s2);
-        }
+        const bool more = kt + GSTAGES - 1 < nk;
+        int s2 = stage + GSTAGES - 1; if (s2 >= GSTAGES) s2 -= GSTAGES;
         const char* sa = smem + stage * STAGE;
         const char* sb = sa + A_BYTES;
 #pragma unroll
         for (int kk = 0; kk < GBK / 16; ++kk) {
+            if (more) issue_part(kt + GSTAGES - 1, s2, kk);
             bf16x8_t xf[2], wf[NB];
 #pragma unroll
             for (int mb = 0; mb < 2; ++mb)
@@ -209,13 +212,11 @@ __global__ __launch_bounds__(GNT) void gemm_conv_glds_kernel(const DcGemmParams 
                 else brow = wn * (32 * NB) + nb * 32;
                 wf[nb] = *reinterpret_cast<const bf16x8_t*>(sb + lds_off2(brow + fr, kk * 2 + fh));
             }
-            __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
                 for (int nb = 0; nb < NB; ++nb)
                     acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[nb], xf[mb], acc[mb][nb], 0, 0, 0);
-            __builtin_amdgcn_s_setprio(0);
         }
         ++stage; if (stage >= GSTAGES) stage = 0;
     }
@@ -316,7 +317,7 @@ __global__ __launch_bounds__(GNT) void gemm_conv_glds_kernel(const DcGemmParams 
 // vmcnt bookkeeping: DMA is counted by hand (asm); the epilogue's loads/stores are compiler-counted. Retirement
 // is in issue order, and every compiler-visible operation is issued AFTER the DMA it could be confused with is
 // already older than the hand-counted window, so each counted wait can only over-wait, never under-wait.
-template <int BN, bool GEGLU, int GSTAGES>
+template <int BN, bool GEGLU, int GSTAGES, int EPI>
 __global__ __launch_bounds__(GNT) void gemm_persist_kernel(const DcGemmParams p) {
     constexpr int NB = BN / 64;
     constexpr int NBX = GEGLU ? NB / 2 : NB;
@@ -376,20 +377,29 @@ __global__ __launch_bounds__(GNT) void gemm_persist_kernel(const DcGemmParams p)
             b_ptr[q] = p.W + (size_t)wrow * p.K + chunk * 8;
         }
     };
-    auto issue_next = [&]() __attribute__((always_inline)) {
+    // quarter `part` of the next K tile's LDS-DMA (see issue_part above); part 3 advances the issue cursor
+    auto issue_next_part = [&](int part) __attribute__((always_inline)) {
         const int k0 = i_kt * GBK;
         const unsigned sa = lds_base + i_stage * STAGE;
         const unsigned sb = sa + A_BYTES;
 #pragma unroll
-        for (int q = 0; q < A_IT; ++q) glds16(a_ptr[q] ? a_ptr[q] + k0 : zero_ptr, sa + (q * 8 + wave) * 1024);
+        for (int q = 0; q < A_IT; ++q)
+            if (q == part) glds16(a_ptr[q] ? a_ptr[q] + k0 : zero_ptr, sa + (q * 8 + wave) * 1024);
 #pragma unroll
-        for (int q = 0; q < B_IT; ++q) glds16(b_ptr[q] + k0, sb + (q * 8 + wave) * 1024);
-        if (++i_stage >= GSTAGES) i_stage = 0;
-        if (++i_kt >= nk) {
-            i_kt = 0;
-            ++i_tile;
-            if (i_tile < nj) set_issue_tile(i_tile);
+        for (int q = 0; q < B_IT; ++q)
+            if ((q & 3) == part) glds16(b_ptr[q] + k0, sb + (q * 8 + wave) * 1024);
+        if (part == 3) {
+            if (++i_stage >= GSTAGES) i_stage = 0;
+            if (++i_kt >= nk) {
+                i_kt = 0;
+                ++i_tile;
+                if (i_tile < nj) set_issue_tile(i_tile);
+            }
         }
+    };
+    auto issue_next = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int part = 0; part < 4; ++part) issue_next_part(part);
     };
 
     f32x16_t acc[2][NB];
@@ -408,7 +418,6 @@ __global__ __launch_bounds__(GNT) void gemm_persist_kernel(const DcGemmParams p)
     if (GSTAGES >= 3 && total > 1) issue_next();
     if (GSTAGES == 4 && total > 2) issue_next();
 
-    const bool out_f32 = (p.flags & DC_GEMM_OUT_F32) != 0;
     int c_tile = 0, c_kt = 0, stage = 0;
     for (int g = 0; g < total; ++g) {
         // tile g has landed once at most the (GSTAGES-2) younger in-flight tiles' DMAs remain outstanding
@@ -418,11 +427,12 @@ __global__ __launch_bounds__(GNT) void gemm_persist_kernel(const DcGemmParams p)
         else wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        if (g + GSTAGES - 1 < total) issue_next();
+        const bool more = g + GSTAGES - 1 < total;
         const char* sa = smem + stage * STAGE;
         const char* sb = sa + A_BYTES;
 #pragma unroll
         for (int kk = 0; kk < GBK / 16; ++kk) {
+            if (more) issue_next_part(kk);
             bf16x8_t xf[2], wf[NB];
 #pragma unroll
             for (int mb = 0; mb < 2; ++mb)
@@ -434,90 +444,164 @@ __global__ __launch_bounds__(GNT) void gemm_persist_kernel(const DcGemmParams p)
                 else brow = wn * (32 * NB) + nb * 32;
                 wf[nb] = *reinterpret_cast<const bf16x8_t*>(sb + lds_off2(brow + fr, kk * 2 + fh));
             }
-            __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
                 for (int nb = 0; nb < NB; ++nb)
                     acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[nb], xf[mb], acc[mb][nb], 0, 0, 0);
-            __builtin_amdgcn_s_setprio(0);
         }
         if (++stage >= GSTAGES) stage = 0;
         if (++c_kt >= nk) {
-            // ---- epilogue of output tile c_tile, straight from registers
+            // ---- epilogue of output tile c_tile.
+            // bf16 outputs go through a 2 KB wave-private LDS patch behind the ring, one 32 x 32 block at a time: the
+            // accumulator layout (lane = row, 4 channels) would store 16-byte pieces of 32 different rows per
+            // instruction, and those scattered stores cost as much as the whole K loop of a short-K GEMM
+            // ([294912 x 320 x 320]: 143 us with them, 66 us without). Read back row-major, a lane owns 8 consecutive
+            // channels and one instruction moves 16 rows x 64 contiguous bytes.
+            // The residual is fetched in the same row-major pattern. LDS operations of one wave execute in order: the
+            // patch needs no barrier. (Tried and dropped: packing the whole tile first, taking the next K tile's wait
+            // and barrier before the stores and loading all residual blocks ahead of the first store - slower.)
             c_kt = 0;
             const int logical = xcd_remap((int)blockIdx.x + c_tile * G, ntiles);
             ++c_tile;
             const int tn = logical % tiles_n, tmi = logical / tiles_n;
             const int m0 = tmi * GBM, n0 = tn * BNOUT;
-#pragma unroll
-            for (int mb = 0; mb < 2; ++mb) {
-                const int m = m0 + wm * 64 + mb * 32 + fr;
+            // lane coordinates re-derived behind an opaque move: otherwise every address below is loop-invariant, gets
+            // hoisted out of the K loop and is kept alive (spilled) across it
+            int lane_e = lane;
+            asm volatile("" : "+v"(lane_e));
+            const int fr_e = lane_e & 31, fh_e = lane_e >> 5;
+
+            // bias / GEGLU / GELU / per-row-group vector / alpha, in the accumulator layout
+            auto finish = [&](int mb, int nb, int q) __attribute__((always_inline)) -> float4 {
+                const int m = m0 + wm * 64 + mb * 32 + fr_e;
                 const float* rv = p.rowvec ? p.rowvec + (size_t)((m < p.M ? m : 0) / p.rows_per_vec) * p.rowvec_ld : nullptr;
+                const int n = n0 + wn * WCOLS + nb * 32 + 8 * q + 4 * fh_e;
+                const bool nok = n < n_out;
+                float4 v = make_float4(acc[mb][nb][4 * q], acc[mb][nb][4 * q + 1], acc[mb][nb][4 * q + 2], acc[mb][nb][4 * q + 3]);
+                if (p.bias && nok) {
+                    const float4 bv = *reinterpret_cast<const float4*>(p.bias + n);
+                    v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+                }
+                if constexpr (GEGLU) {
+                    float4 gt = make_float4(acc[mb][nb + NBX][4 * q], acc[mb][nb + NBX][4 * q + 1],
+                                            acc[mb][nb + NBX][4 * q + 2], acc[mb][nb + NBX][4 * q + 3]);
+                    if (p.bias && nok) {
+                        const float4 bg = *reinterpret_cast<const float4*>(p.bias + (p.N >> 1) + n);
+                        gt.x += bg.x; gt.y += bg.y; gt.z += bg.z; gt.w += bg.w;
+                    }
+                    v.x *= gelu_erf_f(gt.x); v.y *= gelu_erf_f(gt.y); v.z *= gelu_erf_f(gt.z); v.w *= gelu_erf_f(gt.w);
+                }
+                if (p.flags & DC_GEMM_GELU) { v.x = gelu_erf_f(v.x); v.y = gelu_erf_f(v.y); v.z = gelu_erf_f(v.z); v.w = gelu_erf_f(v.w); }
+                if (rv && nok) {
+                    const float4 r4 = *reinterpret_cast<const float4*>(rv + n);
+                    v.x += r4.x; v.y += r4.y; v.z += r4.z; v.w += r4.w;
+                }
+                v.x *= p.alpha; v.y *= p.alpha; v.z *= p.alpha; v.w *= p.alpha;
+                return v;
+            };
+            if constexpr (EPI == 2) {
+                // fp32 outputs (VAE attention scores): direct accumulator-layout stores
 #pragma unroll
-                for (int nb = 0; nb < NBX; ++nb)
+                for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const int n = n0 + wn * WCOLS + nb * 32 + 8 * q + 4 * fh;
-                        if (m >= p.M || n >= n_out) continue;
-                        float4 v = make_float4(acc[mb][nb][4 * q], acc[mb][nb][4 * q + 1], acc[mb][nb][4 * q + 2],
-                                               acc[mb][nb][4 * q + 3]);
-                        if (p.bias) {
-                            const float4 bv = *reinterpret_cast<const float4*>(p.bias + n);
-                            v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+                    for (int nb = 0; nb < NBX; ++nb)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const int m = m0 + wm * 64 + mb * 32 + fr_e;
+                            const int n = n0 + wn * WCOLS + nb * 32 + 8 * q + 4 * fh_e;
+                            const float4 v = finish(mb, nb, q);
+                            if (m < p.M && n < n_out) *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.C) + (size_t)m * p.ldc + n) = v;
                         }
-                        if constexpr (GEGLU) {
-                            float4 gt = make_float4(acc[mb][nb + NBX][4 * q], acc[mb][nb + NBX][4 * q + 1],
-                                                    acc[mb][nb + NBX][4 * q + 2], acc[mb][nb + NBX][4 * q + 3]);
-                            if (p.bias) {
-                                const float4 bg = *reinterpret_cast<const float4*>(p.bias + (p.N >> 1) + n);
-                                gt.x += bg.x; gt.y += bg.y; gt.z += bg.z; gt.w += bg.w;
-                            }
-                            v.x *= gelu_erf_f(gt.x); v.y *= gelu_erf_f(gt.y); v.z *= gelu_erf_f(gt.z); v.w *= gelu_erf_f(gt.w);
+            } else {
+                char* const ebuf = smem + GSTAGES * STAGE + wave * 2048;
+                const int rrow = lane_e >> 2, rc = lane_e & 3;     // read-back coordinates: row inside a 16-row pass, chunk
+                // 32-bit byte offsets from the (uniform) base pointers: one VGPR per (half, pass) row, the n-block is an
+                // instruction immediate (dispatch guarantees M * ld * 2 < 4 GiB, N % 8 == 0)
+                const int ncol = n0 + wn * WCOLS + rc * 8;
+                const char* const rbase = reinterpret_cast<const char*>(p.residual);
+                char* const cbase = reinterpret_cast<char*>(p.C);
+                auto row_off = [&](int mb, int t, int ld) __attribute__((always_inline)) -> unsigned {
+                    int mr = m0 + wm * 64 + mb * 32 + t * 16 + rrow;
+                    if (mr >= p.M) mr = p.M - 1;                    // clamped rows are loaded, never stored
+                    return ((unsigned)mr * (unsigned)ld + (unsigned)(ncol + 8 <= n_out ? ncol : 0)) * 2u;
+                };
+#pragma unroll
+                for (int mb = 0; mb < 2; ++mb) {
+                    unsigned co[2], ro[2];
+                    bool rok[2];
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) {
+                        co[t] = row_off(mb, t, p.ldc);
+                        ro[t] = row_off(mb, t, p.ldr);
+                        rok[t] = m0 + wm * 64 + mb * 32 + t * 16 + rrow < p.M;
+                    }
+#pragma unroll
+                    for (int nb = 0; nb < NBX; ++nb) {
+                        u32x4_t rr[2];
+                        if constexpr (EPI == 1) {
+                            const int nbo = (ncol + nb * 32 + 8 <= n_out) ? nb * 64 : 0;      // stay inside the row
+#pragma unroll
+                            for (int t = 0; t < 2; ++t) rr[t] = *reinterpret_cast<const u32x4_t*>(rbase + ro[t] + nbo);
                         }
-                        if (p.flags & DC_GEMM_GELU) { v.x = gelu_erf_f(v.x); v.y = gelu_erf_f(v.y); v.z = gelu_erf_f(v.z); v.w = gelu_erf_f(v.w); }
-                        if (rv) {
-                            const float4 r4 = *reinterpret_cast<const float4*>(rv + n);
-                            v.x += r4.x; v.y += r4.y; v.z += r4.z; v.w += r4.w;
-                        }
-                        v.x *= p.alpha; v.y *= p.alpha; v.z *= p.alpha; v.w *= p.alpha;
-                        if (out_f32) {
-                            *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.C) + (size_t)m * p.ldc + n) = v;
-                        } else {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {   // row fr, 8-byte slot 2q+fh, XOR-swizzled by an even number per row pair
+                            const float4 v = finish(mb, nb, q);
                             uint2 pk;
                             pk.x = pack_bf2(v.x, v.y);
                             pk.y = pack_bf2(v.z, v.w);
-                            if (p.residual) {
-                                const uint2 rr = *reinterpret_cast<const uint2*>(p.residual + (size_t)m * p.ldr + n);
-                                pk.x = pack_bf2(__uint_as_float(pk.x << 16) + __uint_as_float(rr.x << 16),
-                                                __uint_as_float(pk.x & 0xffff0000u) + __uint_as_float(rr.x & 0xffff0000u));
-                                pk.y = pack_bf2(__uint_as_float(pk.y << 16) + __uint_as_float(rr.y << 16),
-                                                __uint_as_float(pk.y & 0xffff0000u) + __uint_as_float(rr.y & 0xffff0000u));
-                            }
-                            *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.C) + (size_t)m * p.ldc + n) = pk;
+                            *reinterpret_cast<uint2*>(ebuf + fr_e * 64 + (((2 * q + fh_e) ^ (((fr_e >> 1) & 3) << 1)) << 3)) = pk;
                         }
+#pragma unroll
+                        for (int t = 0; t < 2; ++t) {
+                            const int r = t * 16 + rrow;
+                            u32x4_t d = *reinterpret_cast<const u32x4_t*>(ebuf + r * 64 + ((rc ^ ((r >> 1) & 3)) << 4));
+                            if (!rok[t] || ncol + nb * 32 + 8 > n_out) continue;
+                            if constexpr (EPI == 1) {
+#pragma unroll
+                                for (int e = 0; e < 4; ++e)
+                                    d[e] = pack_bf2(__uint_as_float(d[e] << 16) + __uint_as_float(rr[t][e] << 16),
+                                                    __uint_as_float(d[e] & 0xffff0000u) + __uint_as_float(rr[t][e] & 0xffff0000u));
+                            }
+                            *reinterpret_cast<u32x4_t*>(cbase + co[t] + nb * 64) = d;
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
                     }
+                }
             }
             zero_acc();
         }
     }
 }
 
-template <int BN, bool GEGLU>
-int launch_persist(const DcGemmParams& p, hipStream_t stream, int grid) {
-    // ring depth by LDS budget (160 KB): 64-wide 4 x 40 KB, 128-wide 3 x 48 KB, 256/320-wide 2 x 64/72 KB
-    constexpr int ST = (BN == 64) ? 4 : (BN == 128 ? 3 : 2);
-    constexpr size_t lds = (size_t)ST * (GBM * GBK * 2 + BN * GBK * 2);
+template <int BN, bool GEGLU, int EPI>
+int launch_persist_epi(const DcGemmParams& p, hipStream_t stream, int grid) {
+    // ring depth by LDS budget (160 KB minus 8 x 2 KB of epilogue patches): 64-wide 3 x 40 KB, 128-wide 3 x 48 KB,
+    // 256/320-wide 2 x 64/72 KB
+    constexpr int ST = (BN <= 128) ? 3 : 2;
+    constexpr size_t lds = (size_t)ST * (GBM * GBK * 2 + BN * GBK * 2) + 8 * 2048;
+    static_assert(lds <= 163840, "LDS budget");
     static bool configured = false;
     if (!configured) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_persist_kernel<BN, GEGLU, ST>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_persist_kernel<BN, GEGLU, ST, EPI>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
         configured = true;
     }
-    hipLaunchKernelGGL((gemm_persist_kernel<BN, GEGLU, ST>), dim3(grid), dim3(GNT), lds, stream, p);
+    hipLaunchKernelGGL((gemm_persist_kernel<BN, GEGLU, ST, EPI>), dim3(grid), dim3(GNT), lds, stream, p);
     DC_CHECK_LAUNCH();
     return 0;
+}
+
+// epilogue flavour: 0 bf16, 1 bf16 + residual, 2 fp32
+template <int BN, bool GEGLU>
+int launch_persist(const DcGemmParams& p, hipStream_t stream, int grid) {
+    if (p.flags & DC_GEMM_OUT_F32) {
+        if constexpr (GEGLU) return DC_ERR_ARG;
+        else return launch_persist_epi<BN, GEGLU, 2>(p, stream, grid);
+    }
+    if (p.residual) return launch_persist_epi<BN, GEGLU, 1>(p, stream, grid);
+    return launch_persist_epi<BN, GEGLU, 0>(p, stream, grid);
 }
 
 template <int BN, bool GEGLU, int MODE, int GSTAGES>
@@ -564,7 +648,12 @@ int dc_gemm_conv_glds_try(const DcGemmParams& p, hipStream_t stream) {
     static const int force = [] { const char* e = getenv("DC_GEMM_TILE"); return e ? atoi(e) : 0; }();
     static const int persist = [] { const char* e = getenv("DC_GEMM_PERSIST"); return e ? atoi(e) : 1; }();
     if (geglu && p.mode != 0) return DC_ERR_ARG;
-    if (persist && force == 0 && p.mode == 0 && p.K <= persist_max_k()) {
+    // the persistent kernel's row-major epilogue moves 16 bytes per lane
+    const bool out_f32 = (p.flags & DC_GEMM_OUT_F32) != 0;
+    const bool epi16 = out_f32 || ((n_out % 8 == 0) && (p.ldc % 8 == 0) && ((long long)p.M * p.ldc < (1ll << 31)) &&
+                                   ((long long)p.M * p.ldr < (1ll << 31)) && ((uintptr_t)p.C % 16 == 0) &&
+                                   (!p.residual || ((p.ldr % 8 == 0) && ((uintptr_t)p.residual % 16 == 0))));
+    if (persist && force == 0 && p.mode == 0 && epi16 && p.K <= persist_max_k()) {
         // one workgroup per CU; needs at least 2 output tiles per workgroup to have anything to overlap
         static const int wide = [] { const char* e = getenv("DC_GEMM_PERSIST_WIDE"); return e ? atoi(e) : 1; }();
         if (geglu) {

@@ -389,3 +389,45 @@ def test_gemm_geglu_persistent_256(ops):
     h = x.float() @ bf(w).float().t() + b
     val, gate = h.chunk(2, dim=-1)
     assert rel_l2(out, val * F.gelu(gate)) < 4e-3
+
+
+# ---- ragged tile counts for the wide (256 x 320, GEGLU 256 x 256) tiles -------------
+@pytest.mark.parametrize("M,N,K", [(18432, 1280, 1280), (4608 + 33, 1280, 640), (73728, 640, 320), (10000, 320, 2560),
+                                    (256 * 70, 960, 128)])
+def test_gemm_ragged_wide(ops, M, N, K):
+    test_gemm_plain_large(ops, M, N, K)
+
+
+@pytest.mark.parametrize("cfg", [
+    dict(n=32, C=128, Co=1280, H=18, W=32, stride=1, pad=1, ups=0),       # 72 row tiles x 4 = 288 tiles
+    dict(n=32, C=64, Co=640, H=9, W=16, stride=1, pad=1, ups=0),          # 18 x 2 = 36 tiles
+    dict(n=30, C=192, Co=320, H=17, W=23, stride=1, pad=1, ups=0),
+    dict(n=32, C=64, Co=640, H=18, W=16, stride=1, pad=1, ups=1),
+])
+def test_conv3x3_ragged_wide(ops, cfg):
+    test_conv3x3(ops, cfg)
+
+
+def test_tconv3_ragged_wide(ops):
+    B, T, HW, Cc = 2, 16, 577, 640
+    x = bf(rnd(B, Cc, T, HW, 1, seed=1)); w = rnd(Cc, Cc, 3, 1, 1, seed=2, scale=(3 * Cc) ** -0.5); b = rnd(Cc, seed=3)
+    ref = F.conv3d(x.float(), bf(w).float(), b, padding=(1, 0, 0))
+    pw = ops.PackedWeight.tconv3(w, b, DEV)
+    rows = x.permute(0, 2, 3, 4, 1).reshape(-1, Cc).contiguous().to(DEV)
+    out = torch.empty_like(rows)
+    ops.gemm(rows, pw, out, tconv=dict(T=T, HW=HW))
+    assert rel_l2(out, ref.permute(0, 2, 3, 4, 1).reshape(-1, Cc)) < 4e-3
+    out2 = torch.empty_like(rows)
+    ops.gemm(rows, pw, out2, tconv=dict(T=T, HW=HW))
+    assert torch.equal(out, out2)            # fixed summation order: bitwise reproducible
+
+
+def test_gemm_geglu_ragged_wide(ops):
+    M, dim, inner = 18432 + 5, 256, 1280
+    x = bf(rnd(M, dim, seed=1)); w = rnd(2 * inner, dim, seed=2, scale=dim ** -0.5); b = rnd(2 * inner, seed=3, scale=0.1)
+    pw = ops.PackedWeight.linear(w, b, DEV)
+    out = torch.empty(M, inner, dtype=torch.bfloat16, device=DEV)
+    ops.gemm(x.to(DEV), pw, out, geglu=True)
+    h = x.float() @ bf(w).float().t() + b
+    val, gate = h.chunk(2, dim=-1)
+    assert rel_l2(out, val * F.gelu(gate)) < 4e-3
