@@ -24,7 +24,12 @@ class DiagonalGaussianDistribution:
             return self.mode()
         if noise is None:
             noise = torch.randn(self._shape())
-        noise = noise.to(device=dev, dtype=torch.float32).contiguous()
+        # the kernel reads one value per output element: broadcastable noise (the reference computes
+        # mean + std * noise with torch broadcasting) is expanded here, anything else is refused before the launch
+        try:
+            noise = noise.to(device=dev, dtype=torch.float32).expand(self._shape()).contiguous()
+        except RuntimeError as e:
+            raise ValueError(f"noise of shape {tuple(noise.shape)} does not broadcast to {self._shape()}") from e
         z = torch.empty(self._shape(), dtype=torch.float32, device=dev)
         return ops.vae_sample(self._rows, noise, z, N=self._N, zc=self._zc, HW=self._H * self._W, scale=1.0)
 

@@ -20,6 +20,7 @@ import torch.nn as nn
 
 from ... import ops
 from ...utils.utils import instantiate_from_config
+from ..distributions import DiagonalGaussianDistribution
 from ..modules.networks.openaimodel3d import C_IN_PAD
 from .utils_diffusion import make_beta_schedule, rescale_zero_terminal_snr
 
@@ -206,11 +207,11 @@ class LatentDiffusion(DDPM):
             return getattr(m, self.cond_stage_forward)(c)
         if hasattr(m, "encode") and callable(m.encode):
             c = m.encode(c)
-            return c.mode() if hasattr(c, "mode") else c
+            return c.mode() if isinstance(c, DiagonalGaussianDistribution) else c
         return m(c)
 
     def get_first_stage_encoding(self, encoder_posterior, noise=None):
-        if hasattr(encoder_posterior, "sample"):
+        if isinstance(encoder_posterior, DiagonalGaussianDistribution):
             z = encoder_posterior.sample(noise=noise)
         elif isinstance(encoder_posterior, torch.Tensor):
             z = encoder_posterior

@@ -516,7 +516,7 @@ class UNetModel(nn.Module):
             # cross-attention (conv_in, init_attn, the first ResBlock, the first SpatialTransformer's self-attention)
             # is computed ONCE on B/nrep clips and replicated; results are bit-identical to the full batch.
             B1 = B // nrep
-            g1 = dict(g, B=B1, F=B1 * T)
+            g1 = dict(g, B=B1, F=B1 * T, emb=emb[:B1])      # the branches share timestep and fs: rows 0..B1 of emb
             h = self._run_block(down_path[0], Wt["in"][0], h[:B1 * T * H * W], g1, "in0")
             if self.addition_attention:
                 h = self._temporal(Wt["init_attn"], h, g1, 8, "init_attn")

@@ -196,6 +196,19 @@ def gemm(a, pw, out, *, M=None, residual=None, rowvec=None, rows_per_vec=1, gegl
     n_out = pw.N // 2 if geglu else pw.N
     if out.shape[1] < n_out:
         raise ValueError(f"gemm: out has {out.shape[1]} columns, need {n_out}")
+    # row extents the launch addresses (the C ABI takes raw pointers)
+    if out.shape[0] < p.M or (residual is not None and (residual.shape[0] < p.M or residual.shape[1] < n_out)):
+        raise ValueError(f"gemm: out/residual have fewer than M={p.M} rows (or residual fewer than {n_out} columns)")
+    if p.mode == 1:
+        if p.M % (p.OH * p.OW) != 0 or a.shape[0] < (p.M // (p.OH * p.OW)) * p.IH * p.IW:
+            raise ValueError(f"conv3x3: M={p.M} output rows need {p.M // (p.OH * p.OW)} frames of {p.IH}x{p.IW} input rows, "
+                             f"activation has {a.shape[0]}")
+    elif a.shape[0] < p.M:
+        raise ValueError(f"gemm: activation has {a.shape[0]} rows, M={p.M}")
+    if p.mode == 2 and (p.M % (p.T * p.HW) != 0 or a.shape[1] < pw.Cin):
+        raise ValueError("tconv: M must be a multiple of T*HW and the activation at least Cin wide")
+    if rowvec is not None and (rowvec.shape[0] * rows_per_vec < p.M or rowvec.shape[1] < n_out):
+        raise ValueError("gemm: rowvec does not cover every row group / output column")
     if _TRACE is not None:
         t128 = (pw.N + 127) // 128 * 128
         variant = "gemm_conv<128,geglu>" if geglu else ("gemm_conv<64>" if (pw.N <= 64 or t128 / pw.N > 1.15) else "gemm_conv<128>")
@@ -223,8 +236,21 @@ def _gn_workspace(device, nbytes):
     return buf
 
 
+def _need(t, n, name):
+    """The C ABI takes raw pointers: refuse operands smaller than the extent the kernel will touch."""
+    if t is not None and t.numel() < n:
+        raise ValueError(f"{name}: {t.numel()} elements, the launch reads/writes {n}")
+
+
+def _need_rows(t, rows, cols, name):
+    if t.shape[0] < rows or t.shape[1] < cols:
+        raise ValueError(f"{name}: shape {tuple(t.shape)}, the launch addresses [{rows}, {cols}]")
+
+
 def groupnorm(x, y, gamma, beta, *, groups, n_inst, rows_per_inst, eps, silu):
     _rows(x, "x"); _rows(y, "y")
+    _need_rows(x, n_inst * rows_per_inst, gamma.numel(), "x"); _need_rows(y, n_inst * rows_per_inst, gamma.numel(), "y")
+    _need(beta, gamma.numel(), "beta")
     Cc = gamma.numel()
     l = _hip.lib()
     ws = _gn_workspace(x.device, int(l.dc_groupnorm_workspace_bytes(n_inst, groups, rows_per_inst)))
@@ -236,6 +262,7 @@ def groupnorm(x, y, gamma, beta, *, groups, n_inst, rows_per_inst, eps, silu):
 
 def layernorm(x, y, gamma, beta, eps=1e-5):
     _rows(x, "x"); _rows(y, "y")
+    _need_rows(x, x.shape[0], gamma.numel(), "x"); _need_rows(y, x.shape[0], gamma.numel(), "y"); _need(beta, gamma.numel(), "beta")
     _launch("layernorm", 0.0, 4.0 * x.shape[0] * gamma.numel(), _hip.lib().dc_layernorm, _ptr(x), x.stride(0), _ptr(y),
             y.stride(0), _ptr(gamma), _ptr(beta), x.shape[0], gamma.numel(), eps, stream_ptr())
     return y
@@ -247,6 +274,10 @@ def flash_attn(q, k, v, o, *, batch, heads, Lq, Lk, scale, accumulate=False, acc
     q_bstride / kv_bstride: rows between consecutive batch items (default Lq / Lk)."""
     for t, n in ((q, "q"), (k, "k"), (v, "v"), (o, "o")):
         _rows(t, n)
+    qb = Lq if q_bstride is None else q_bstride
+    kb = Lk if kv_bstride is None else kv_bstride
+    _need_rows(q, (batch - 1) * qb + Lq, heads * 64, "q"); _need_rows(o, (batch - 1) * qb + Lq, heads * 64, "o")
+    _need_rows(k, (batch - 1) * kb + Lk, heads * 64, "k"); _need_rows(v, (batch - 1) * kb + Lk, heads * 64, "v")
     _launch("flash_attn_d64(self)" if Lk > 128 else "flash_attn_d64(cross)", 4.0 * batch * heads * Lq * Lk * 64,
             2.0 * batch * heads * 64 * (2 * Lq + 2 * Lk), _hip.lib().dc_flash_attn_d64, _ptr(q), _ptr(k), _ptr(v), _ptr(o),
             q.stride(0), k.stride(0), v.stride(0), o.stride(0), batch, heads, Lq, Lk,
@@ -257,6 +288,7 @@ def flash_attn(q, k, v, o, *, batch, heads, Lq, Lk, scale, accumulate=False, acc
 
 def temporal_attn(qkv, o, *, B, T, HW, heads, scale):
     _rows(qkv, "qkv"); _rows(o, "o")
+    _need_rows(qkv, B * T * HW, 3 * heads * 64, "qkv"); _need_rows(o, B * T * HW, heads * 64, "o")
     _launch("temporal_attn_d64", 4.0 * B * HW * heads * T * T * 64, 2.0 * B * T * HW * heads * 64 * 4,
             _hip.lib().dc_temporal_attn_d64, _ptr(qkv), qkv.stride(0), _ptr(o), o.stride(0), B, T, HW, heads, scale,
             stream_ptr())
@@ -265,6 +297,8 @@ def temporal_attn(qkv, o, *, B, T, HW, heads, scale):
 
 def gemv_small(x, pw, out, *, act_in=0, act_out=0, accumulate=False):
     """x [M<=8, K] fp32, out [M, N] fp32."""
+    if x.shape[0] > 8 or x.shape[1] < pw.K or out.shape[0] < x.shape[0] or out.shape[1] < pw.N:
+        raise ValueError(f"gemv_small: x {tuple(x.shape)}, weight [{pw.N}, {pw.K}], out {tuple(out.shape)}")
     check(_hip.lib().dc_gemv_small(_ptr(x), x.stride(0), _ptr(pw.w), _ptr(pw.bias), _ptr(out), out.stride(0),
                                    x.shape[0], pw.N, pw.K, act_in, act_out, 1 if accumulate else 0, stream_ptr()),
           "dc_gemv_small")
@@ -272,24 +306,29 @@ def gemv_small(x, pw, out, *, act_in=0, act_out=0, accumulate=False):
 
 
 def timestep_embedding(t_table, out, dim, *, t_index=None, t_stride=0, max_period=10000.0):
+    if out.shape[1] < dim or t_table.numel() < out.shape[0]:
+        raise ValueError(f"timestep_embedding: out {tuple(out.shape)}, dim {dim}, table of {t_table.numel()} entries")
     check(_hip.lib().dc_timestep_embedding(_ptr(t_table), _ptr(t_index), t_stride, _ptr(out), out.shape[0], dim,
                                            max_period, stream_ptr()), "dc_timestep_embedding")
     return out
 
 
 def pack_latent(x, cc, out, *, B, Cx, Cc, T, HW, nrep=1):
+    _need(x, B * Cx * T * HW, "x"); _need(cc, B * Cc * T * HW, "c_concat"); _need_rows(out, nrep * B * T * HW, Cx + Cc, "out")
     check(_hip.lib().dc_pack_latent(_ptr(x), _ptr(cc), _ptr(out), B, Cx, Cc, T, HW, out.stride(0), nrep,
                                     stream_ptr()), "dc_pack_latent")
     return out
 
 
 def nchw_to_rows(x, out, *, N, Cc, HW, scale=1.0):
+    _need(x, N * Cc * HW, "x"); _need_rows(out, N * HW, Cc, "out")
     check(_hip.lib().dc_nchw_to_rows(_ptr(x), _ptr(out), N, Cc, HW, out.stride(0), scale, stream_ptr()),
           "dc_nchw_to_rows")
     return out
 
 
 def rows_to_nchw(rows, y, *, N, Cc, HW, scale=1.0):
+    _need_rows(rows, N * HW, Cc, "rows"); _need(y, N * Cc * HW, "y")
     check(_hip.lib().dc_rows_to_nchw(_ptr(rows), rows.stride(0), 1 if rows.dtype == torch.float32 else 0, _ptr(y),
                                      N, Cc, HW, scale, stream_ptr()), "dc_rows_to_nchw")
     return y
@@ -319,6 +358,7 @@ def add_rows(a, b, y):
 
 
 def build_context(ctx, out, *, B, T, n_text, L, D):
+    _need(ctx, B * (n_text + T * L) * D, "context"); _need(out, B * T * (n_text + L) * D, "out")
     check(_hip.lib().dc_build_context(_ptr(ctx), _ptr(out), B, T, n_text, L, D, stream_ptr()), "dc_build_context")
     return out
 
@@ -330,6 +370,7 @@ def softmax_rows(x, y):
 
 
 def vae_sample(moments, noise, z, *, N, zc, HW, scale):
+    _need_rows(moments, N * HW, 2 * zc, "moments"); _need(noise, N * zc * HW, "noise"); _need(z, N * zc * HW, "z")
     check(_hip.lib().dc_vae_sample(_ptr(moments), moments.stride(0), _ptr(noise), _ptr(z), N, zc, HW, scale,
                                    stream_ptr()), "dc_vae_sample")
     return z

@@ -47,8 +47,21 @@ def install_stubs():
     tvu = types.ModuleType("torchvision.utils")
     tvu.make_grid = lambda *a, **k: None
     tv.utils = tvu
+    tvt = types.ModuleType("torchvision.transforms")      # imported by scripts/evaluation/inference.py, unused on the path
+    tv.transforms = tvt
     sys.modules["torchvision"] = tv
     sys.modules["torchvision.utils"] = tvu
+    sys.modules["torchvision.transforms"] = tvt
+    pl.seed_everything = lambda seed: torch.manual_seed(seed)
+    oc = types.ModuleType("omegaconf")                      # idem (only run_inference reads the YAML through it)
+    oc.OmegaConf = type("OmegaConf", (), {})
+    sys.modules.setdefault("omegaconf", oc)
+    if "PIL" not in sys.modules:
+        try:
+            import PIL  # noqa: F401
+        except ImportError:
+            pil = types.ModuleType("PIL"); pil.Image = types.ModuleType("PIL.Image")
+            sys.modules["PIL"] = pil; sys.modules["PIL.Image"] = pil.Image
     sys.path.insert(0, REF)
 
 
@@ -160,7 +173,7 @@ def gen_ae():
              param_names=np.array(sorted(shapes)), yaml_params=np.array(yaml.safe_dump(dd)))
 
 
-def build_lvd(config_name, unet_params=None, ae_dd=None):
+def build_lvd(config_name, unet_params=None, ae_dd=None, conditioners=None):
     """LatentVisualDiffusion from a released YAML with small nets and Identity conditioners."""
     from utils.utils import instantiate_from_config
     cfg = yaml.safe_load(open(os.path.join(REF, "configs", config_name)))
@@ -177,6 +190,7 @@ def build_lvd(config_name, unet_params=None, ae_dd=None):
     p["cond_stage_config"] = {"target": "torch.nn.Identity"}
     p["img_cond_stage_config"] = {"target": "torch.nn.Identity"}
     p["image_proj_stage_config"] = {"target": "torch.nn.Identity"}
+    p.update(conditioners or {})
     model = instantiate_from_config(to_attr(m)).eval()
     return model, p
 
@@ -316,6 +330,60 @@ def gen_first_stage():
     save("first_stage", video=vid, noise=torch.cat(noise, 0), z=z, rec=rec, scale_factor=np.array(model.scale_factor))
 
 
+def gen_harness():
+    """scripts/evaluation/inference.py:image_guided_synthesis of the reference, driven end to end on CPU: toy CLIP
+    stand-ins (tests/golden_cfg.py) -> reference Resampler -> conditioning assembly -> DDIM loop -> per-frame AE
+    decode. Cases: (a) 512 config, 2-branch CFG 7.5, guidance rescale, eta=1, text prompt; (b) 256 config, interp
+    mode (first/last-frame concat), 3-branch guidance (multiple_cond_cfg, cfg_img=2), eta=0."""
+    import importlib.util
+    from tests.golden_cfg import TINY_RESAMPLER
+    spec = importlib.util.spec_from_file_location("ref_inference", os.path.join(REF, "scripts", "evaluation", "inference.py"))
+    inf = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(inf)
+    import lvdm.models.samplers.ddim as ddim_mod
+    import lvdm.models.samplers.ddim_multiplecond as mc_mod
+    inf.DDIMSampler = cpu_sampler_cls(ddim_mod.DDIMSampler)
+    inf.DDIMSampler_multicond = cpu_sampler_cls(mc_mod.DDIMSampler)
+    for tag, cname, kw in (
+            ("a", "inference_512_v1.0.yaml", dict(ddim_steps=5, ddim_eta=1.0, unconditional_guidance_scale=7.5, fs=24,
+                                                  text_input=True, timestep_spacing="uniform_trailing", guidance_rescale=0.7)),
+            ("b", "inference_256_v1.0.yaml", dict(ddim_steps=4, ddim_eta=0.0, unconditional_guidance_scale=7.5, fs=3,
+                                                  text_input=False, multiple_cond_cfg=True, cfg_img=2.0, interp=True,
+                                                  timestep_spacing="uniform", guidance_rescale=0.0))):
+        extra = dict(image_cross_attention_scale_learnable=True) if "256" in cname else {}
+        model, p = build_lvd(cname, dict(TINY_UNET, **extra), TINY_AE,
+                             conditioners=dict(cond_stage_config={"target": "tests.golden_cfg.ToyTextEmbedder"},
+                                               img_cond_stage_config={"target": "tests.golden_cfg.ToyImageEmbedder"},
+                                               image_proj_stage_config={"target": "lvdm.modules.encoders.resampler.Resampler",
+                                                                        "params": dict(TINY_RESAMPLER)}))
+        load_recipe_weights(model.model.diffusion_model, seed=11)
+        load_recipe_weights(model.first_stage_model, seed=13)
+        load_recipe_weights(model.image_proj_model, seed=14)
+        b, t, H, W = 1, 4, 64, 64
+        h, w = H // 8, W // 8
+        videos = rnd(b, 3, t, H, W, seed=101).clamp(-1, 1)
+        if kw.get("interp"):
+            videos[:, :, 1:-1] = 0.0
+        x_T = rnd(b, 4, t, h, w, seed=102)
+        S = kw["ddim_steps"]
+        noises = [rnd(b, 4, t, h, w, seed=110 + i) for i in range(S)]
+        ae_noise = [rnd(1, 4, h, w, seed=120 + i) for i in range(b * t)]
+        it_n, it_a = iter(noises), iter(ae_noise)
+        ddim_mod.noise_like = lambda shp, dev, rep=False: next(it_n)
+        mc_mod.noise_like = ddim_mod.noise_like
+        orig = torch.randn
+        torch.randn = lambda *a, **k: next(it_a)        # only DiagonalGaussianDistribution.sample draws it (x_T is injected)
+        try:
+            with torch.no_grad():
+                out = inf.image_guided_synthesis(model, ["a corgi running on the beach"], videos, [b, 4, t, h, w],
+                                                 n_samples=1, x_T=x_T, **kw)
+        finally:
+            torch.randn = orig
+        assert out.shape == (b, 1, 3, t, H, W), out.shape
+        save(f"harness_{tag}", videos=videos, x_T=x_T, noises=torch.stack(noises), ae_noise=torch.cat(ae_noise, 0), out=out,
+             kwargs=np.array(yaml.safe_dump(kw)))
+
+
 def gen_resampler():
     """Reference Resampler: a narrow one and the released configuration (dim 1024, depth 4, 12 heads, 16 queries x 16
     frames) with recipe weights."""
@@ -333,7 +401,8 @@ def gen_resampler():
 
 
 GENS = dict(resampler=gen_resampler, unet_tiny=gen_unet_tiny, unet_fullwidth=gen_unet_fullwidth, ae=gen_ae, schedules=gen_schedules,
-            p_sample=gen_p_sample_known_answers, trajectory=gen_trajectory, first_stage=gen_first_stage)
+            p_sample=gen_p_sample_known_answers, trajectory=gen_trajectory, first_stage=gen_first_stage,
+            harness=gen_harness)
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()

@@ -98,6 +98,49 @@ def test_released_yaml_instantiates_with_reference_keys():
         assert yaml.safe_load(open(ref)) == cfg
 
 
+def test_load_model_checkpoint_key_conventions(tmp_path):
+    """inference.py:34-59: Lightning {"state_dict": ...} strict load, the 256-release `framestride_embed` rename, and
+    the DeepSpeed {"module": {"_forward_module.<key>": ...}} form. Host-side only (weights stay on the CPU)."""
+    from collections import OrderedDict
+    from dynamicrafter_amd.scripts.evaluation.inference import load_model_checkpoint
+    from dynamicrafter_amd.utils.utils import instantiate_from_config
+    from tests.golden_cfg import TINY_AE, TINY_UNET
+
+    def build():
+        cfg = yaml.safe_load(open(os.path.join(ROOT, "dynamicrafter_amd", "configs", "inference_256_v1.0.yaml")))
+        p = cfg["model"]["params"]
+        p["unet_config"]["params"] = dict(TINY_UNET, image_cross_attention_scale_learnable=True)
+        p["first_stage_config"]["params"]["ddconfig"] = dict(TINY_AE)
+        for k in ("cond_stage_config", "img_cond_stage_config", "image_proj_stage_config"):
+            p[k] = {"target": "torch.nn.Identity"}
+        return instantiate_from_config(cfg["model"])
+
+    src = build()
+    g = torch.Generator().manual_seed(5)
+    sd = OrderedDict((k, torch.empty_like(v).normal_(generator=g) if v.is_floating_point() else v.clone())
+                     for k, v in src.state_dict().items())
+    assert any("fps_embedding" in k for k in sd) and any("temopral_conv" in k for k in sd)     # reference spellings
+
+    def check(m):
+        got = m.state_dict()
+        assert list(got) == list(sd)
+        assert all(torch.equal(got[k], sd[k]) for k in sd)
+
+    # (1) Lightning checkpoint from a file
+    f = tmp_path / "model.ckpt"
+    torch.save({"state_dict": sd, "epoch": 3}, f)
+    check(load_model_checkpoint(build(), str(f)))
+    # (2) 256-release key name
+    old = OrderedDict((k.replace("fps_embedding", "framestride_embed"), v) for k, v in sd.items())
+    check(load_model_checkpoint(build(), {"state_dict": old}))
+    # (3) DeepSpeed
+    check(load_model_checkpoint(build(), {"module": OrderedDict(("_forward_module." + k, v) for k, v in sd.items())}))
+    # a wrong key still fails loudly (strict)
+    bad = OrderedDict(sd); bad["model.diffusion_model.nonexistent.weight"] = torch.zeros(1)
+    with pytest.raises(RuntimeError):
+        load_model_checkpoint(build(), {"state_dict": bad})
+
+
 def test_unsupported_configuration_is_loud():
     from dynamicrafter_amd.lvdm.modules.networks.openaimodel3d import UNetModel
     from tests.golden_cfg import TINY_UNET
