@@ -83,7 +83,7 @@ class AutoencoderKL(nn.Module):
             self.monitor = monitor
         attach_params(self, _ae_shapes(dd, embed_dim))
         self._packed = None
-        self._bufs = {}
+        self._arena = ops.Arena()
         self.register_load_state_dict_post_hook(lambda m, k: setattr(m, "_packed", None))
         if ckpt_path is not None:
             sd = torch.load(ckpt_path, map_location="cpu")
@@ -109,12 +109,7 @@ class AutoencoderKL(nn.Module):
         return parts[-1] in node._parameters
 
     def _buf(self, tag, rows, cols, dtype=_BF16, device=None, zero=False):
-        key = (tag, rows, cols, dtype)
-        b = self._bufs.get(key)
-        if b is None:
-            b = (torch.zeros if zero else torch.empty)((rows, cols), dtype=dtype, device=device)
-            self._bufs[key] = b
-        return b
+        return self._arena.get(tag, rows, cols, dtype, device, zero=zero)
 
     def _pack(self, device):
         f32 = lambda n: self._p(n).detach().to(device=device, dtype=torch.float32).contiguous()

@@ -47,7 +47,7 @@ class Resampler(nn.Module):
         with torch.no_grad():
             self.latents.copy_(torch.randn(1, nq, dim, device=self.latents.device) / dim ** 0.5)
         self._packed = None
-        self._bufs = {}
+        self._arena = ops.Arena()
         self.register_load_state_dict_post_hook(lambda m, k: setattr(m, "_packed", None))
 
     def _p(self, name):
@@ -58,12 +58,7 @@ class Resampler(nn.Module):
         return node._parameters[parts[-1]]
 
     def _buf(self, tag, rows, cols, dtype=_BF16, device=None):
-        key = (tag, rows, cols, dtype)
-        b = self._bufs.get(key)
-        if b is None:
-            b = torch.empty((rows, cols), dtype=dtype, device=device)
-            self._bufs[key] = b
-        return b
+        return self._arena.get(tag, rows, cols, dtype, device)
 
     def packed(self, device):
         if self._packed is not None and self._packed["device"] == device:

@@ -171,22 +171,7 @@ def _shape_table(cfg):
     return t
 
 
-class _Arena:
-    """Named, shape-keyed device scratch; allocated on first use, stable afterwards (graph-safe)."""
-
-    def __init__(self):
-        self._bufs = {}
-
-    def get(self, tag, rows, cols, dtype=_BF16, device=None):
-        key = (tag, rows, cols, dtype)
-        b = self._bufs.get(key)
-        if b is None:
-            b = torch.empty((rows, cols), dtype=dtype, device=device)
-            self._bufs[key] = b
-        return b
-
-    def nbytes(self):
-        return sum(b.numel() * b.element_size() for b in self._bufs.values())
+_Arena = ops.Arena
 
 
 class UNetModel(nn.Module):

@@ -5,6 +5,7 @@ current torch stream. Activations are channels-last bf16 rows: 2-D tensors [rows
 Nothing here computes with torch.
 """
 import ctypes as C
+import os
 import math
 
 import torch
@@ -222,6 +223,56 @@ def gemm(a, pw, out, *, M=None, residual=None, rowvec=None, rows_per_vec=1, gegl
     else:
         check(_hip.lib().dc_gemm_conv(C.byref(p), stream_ptr()), "dc_gemm_conv")
     return out
+
+
+class Arena:
+    """Named, shape-keyed device scratch: allocated on first use, stable afterwards (graph-safe).
+
+    DC_ARENA_GUARD=1 (debugging / tests): every buffer is carved out of a larger allocation with `GUARD` sentinel
+    rows before and after it; `check()` raises if a launch wrote outside its buffer. The kernels take raw pointers,
+    so this is the only place an overrun of a scratch buffer can be made visible."""
+    GUARD = 8
+
+    def __init__(self):
+        self._bufs = {}
+        self._guarded = {}
+        self.guard = os.environ.get("DC_ARENA_GUARD", "0") == "1"
+
+    def get(self, tag, rows, cols, dtype=_BF16, device=None, zero=False):
+        key = (tag, rows, cols, dtype)
+        b = self._bufs.get(key)
+        if b is None:
+            if self.guard:
+                G = self.GUARD
+                whole = torch.empty((rows + 2 * G, cols), dtype=dtype, device=device)
+                whole.fill_(self._sentinel(dtype))
+                b = whole[G:G + rows]
+                if zero:
+                    b.zero_()
+                self._guarded[key] = whole
+            else:
+                b = (torch.zeros if zero else torch.empty)((rows, cols), dtype=dtype, device=device)
+            self._bufs[key] = b
+        return b
+
+    @staticmethod
+    def _sentinel(dtype):
+        return 12345.0 if dtype.is_floating_point else 0x5a
+
+    def check(self):
+        """Verify the guard rows of every buffer (guard mode only). Synchronises."""
+        bad = []
+        for (tag, rows, cols, dtype), whole in self._guarded.items():
+            G = self.GUARD
+            ref = torch.full((1,), self._sentinel(dtype), dtype=dtype, device=whole.device)
+            if not (bool((whole[:G] == ref).all()) and bool((whole[G + rows:] == ref).all())):
+                bad.append(f"{tag}[{rows}x{cols} {dtype}]")
+        if bad:
+            raise RuntimeError("scratch buffers overrun: " + ", ".join(bad))
+        return len(self._guarded)
+
+    def nbytes(self):
+        return sum(b.numel() * b.element_size() for b in self._bufs.values())
 
 
 _gn_ws = {}

@@ -356,3 +356,35 @@ def test_image_guided_synthesis_vs_reference(tag, cname):
     assert torch.isfinite(out).all()
     assert rel_l2(out, g["out"]) < 1e-1
     assert torch.equal(videos, T(g["videos"]))       # inputs are not mutated
+
+
+@pytest.mark.parametrize("hw", [8, 16])
+def test_no_scratch_buffer_overrun(monkeypatch, hw):
+    """Every scratch buffer of the UNet / AE / Resampler is allocated between sentinel rows (DC_ARENA_GUARD=1) and the
+    sentinels must survive 2- and 3-branch sampling (shared guidance prefix on), encode, decode and the projector.
+    Regression for the shared-prefix embedding overrun (nb rows written into a 1-row buffer)."""
+    monkeypatch.setenv("DC_ARENA_GUARD", "1")
+    from dynamicrafter_amd.lvdm.models.samplers.ddim import DDIMSampler
+    from dynamicrafter_amd.lvdm.modules.encoders.resampler import Resampler
+    from tests.golden_cfg import TINY_RESAMPLER
+    model = _tiny_lvd("inference_256_v1.0.yaml", dict(image_cross_attention_scale_learnable=True))
+    g = torch.Generator().manual_seed(3)
+    b, t = 1, 4
+    mk = lambda: {"c_crossattn": [torch.randn(b, 77 + 16 * t, 128, generator=g).to(DEV)],
+                  "c_concat": [(torch.randn(b, 4, t, hw, hw, generator=g) * 0.2).to(DEV)]}
+    cond, uc, uc2 = mk(), mk(), mk()
+    uc["c_concat"] = uc2["c_concat"] = cond["c_concat"]                 # shared prefix applies
+    for extra in (dict(cfg_img=2.0, unconditional_conditioning_img_nonetext=uc2), {}):
+        out, _ = DDIMSampler(model).sample(S=2, batch_size=b, shape=(4, t, hw, hw), conditioning=cond, verbose=False,
+                                           unconditional_guidance_scale=7.5, unconditional_conditioning=uc, eta=0.0,
+                                           x_T=torch.randn(b, 4, t, hw, hw, generator=g).to(DEV), **extra)
+        assert torch.isfinite(out).all()
+    vid = torch.randn(1, 3, t, 8 * hw, 8 * hw, generator=g).clamp(-1, 1).to(DEV)
+    z = model.encode_first_stage(vid)
+    rec = model.decode_first_stage(z)
+    assert torch.isfinite(rec).all()
+    rs = recipe_load(Resampler(**TINY_RESAMPLER), 14).to(DEV)
+    y = rs(torch.randn(2, 9, 64, generator=g).to(DEV))
+    assert torch.isfinite(y).all()
+    n = model.model.diffusion_model._arena.check() + model.first_stage_model._arena.check() + rs._arena.check()
+    assert n > 50
