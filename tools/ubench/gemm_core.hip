@@ -167,6 +167,115 @@ void run(const char* name, const char* A, const char* W, float* sink) {
     fflush(stdout);
 }
 
+
+// ---- one wave per SIMD: 256 threads (4 waves as 2 x 2), wave tile 128 x (BN/2): 4 x NB MFMA blocks, 512-register budget.
+// Fragments double-buffered across the 16-wide K steps; LDS-DMA spread (each wave issues 2x the pieces).
+template <int BN, int STG, bool DMA, bool FRAGDB>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
+void core1(const char* __restrict__ A, const char* __restrict__ W, int iters, int kwrap, float* sink) {
+    constexpr int NB = BN / 64;
+    constexpr int A_BYTES = 256 * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
+    constexpr int A_IT = 8, B_IT = BN / 32, LOADS = A_IT + B_IT;          // per wave: 256 rows / (4 waves * 8 rows)
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1, fr = lane & 31, fh = lane >> 5;
+    const unsigned lds_base = (unsigned)(unsigned long)((lds_char_t*)smem);
+    const int srow = lane >> 3, pchunk = lane & 7;
+    const int K = kwrap * 64;
+    const char* a_ptr[A_IT];
+    const char* b_ptr[B_IT];
+#pragma unroll
+    for (int q = 0; q < A_IT; ++q) {
+        const int r = (q * 4 + wave) * 8 + srow;
+        a_ptr[q] = A + ((size_t)r * K + (pchunk ^ ((r >> 1) & 7)) * 8) * 2;
+    }
+#pragma unroll
+    for (int q = 0; q < B_IT; ++q) {
+        const int r = (q * 4 + wave) * 8 + srow;
+        b_ptr[q] = W + ((size_t)r * K + (pchunk ^ ((r >> 1) & 7)) * 8) * 2;
+    }
+    int i_kt = 0, i_stage = 0;
+    auto issue_part = [&](int part) __attribute__((always_inline)) {        // part 0..3
+        const int k0 = i_kt * 128;
+        const unsigned sa = lds_base + i_stage * STAGE, sb = sa + A_BYTES;
+#pragma unroll
+        for (int q = 0; q < A_IT; ++q) if ((q & 3) == part) glds16(a_ptr[q] + k0, sa + (q * 4 + wave) * 1024);
+#pragma unroll
+        for (int q = 0; q < B_IT; ++q) if ((q & 3) == part) glds16(b_ptr[q] + k0, sb + (q * 4 + wave) * 1024);
+        if (part == 3) { if (++i_stage >= STG) i_stage = 0; if (++i_kt >= kwrap) i_kt = 0; }
+    };
+    f32x16_t acc[4][NB];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < NB; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    for (int i = tid; i < STG * STAGE / 4; i += 256) reinterpret_cast<unsigned*>(smem)[i] = 0x3c003c00u;
+    __syncthreads();
+    if (DMA) { for (int p = 0; p < 4; ++p) issue_part(p); if (STG >= 3) for (int p = 0; p < 4; ++p) issue_part(p); }
+    bf16x8_t xf[2][4], wf[2][NB];
+    auto load_frags = [&](int buf, const char* sa, const char* sb, int kk) __attribute__((always_inline)) {
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb)
+            xf[buf][mb] = *reinterpret_cast<const bf16x8_t*>(sa + lds_off(wm * 128 + mb * 32 + fr, kk * 2 + fh));
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+            wf[buf][nb] = *reinterpret_cast<const bf16x8_t*>(sb + lds_off(wn * 32 * NB + nb * 32 + fr, kk * 2 + fh));
+    };
+    int stage = 0;
+    for (int g = 0; g < iters; ++g) {
+        if (DMA) { if (STG >= 3) wait_vm<LOADS>(); else wait_vm<0>(); }
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        const char* sa = smem + stage * STAGE;
+        const char* sb = sa + A_BYTES;
+        if (FRAGDB) load_frags(0, sa, sb, 0);
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            if (DMA) issue_part(kk);
+            const int cur = FRAGDB ? (kk & 1) : 0;
+            if (FRAGDB) { if (kk < 3) load_frags(cur ^ 1, sa, sb, kk + 1); }
+            else load_frags(0, sa, sb, kk);
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb)
+                    acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[cur][nb], xf[cur][mb], acc[mb][nb], 0, 0, 0);
+        }
+        if (++stage >= STG) stage = 0;
+    }
+    wait_vm<0>();
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < NB; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s += acc[i][j][r];
+    if (s == 123.456f) sink[0] = s;
+}
+
+template <int BN, int STG, bool DMA, bool FRAGDB>
+void run1(const char* name, const char* A, const char* W, float* sink) {
+    const int iters = 4000, grid = 256, kwrap = 16;
+    const size_t lds = (size_t)STG * (256 * 128 + BN * 128);
+    auto fn = &core1<BN, STG, DMA, FRAGDB>;
+    hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    hipLaunchKernelGGL(fn, dim3(grid), dim3(256), lds, 0, A, W, 200, kwrap, sink);
+    hipDeviceSynchronize();
+    hipEventRecord(e0);
+    hipLaunchKernelGGL(fn, dim3(grid), dim3(256), lds, 0, A, W, iters, kwrap, sink);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    const double flop = 2.0 * 256 * BN * 64 * (double)iters * grid;
+    printf("1 wave/SIMD BN=%3d STG=%d %-22s %8.3f ms  %6.0f ns/Ktile  %7.0f TF/s-equivalent\n", BN, STG, name, ms,
+           ms * 1e6 / iters, flop / ms / 1e9);
+    fflush(stdout);
+}
+
 template <int BN, int STG>
 void suite(const char* A, const char* W, float* sink) {
     run<BN, STG, true, true, true, true>("full", A, W, sink);
@@ -190,8 +299,16 @@ int main() {
     hipMalloc(&A, 8 << 20); hipMemset(A, 0x3c, 8 << 20);
     hipMalloc(&W, 8 << 20); hipMemset(W, 0x3c, 8 << 20);
     hipMalloc(&sink, 64);
-    suite<320, 2>(A, W, sink);
-    suite<256, 2>(A, W, sink);
-    suite<128, 3>(A, W, sink);
+    run1<320, 2, true, true>("full fragdb", A, W, sink);
+    run1<320, 2, true, false>("full", A, W, sink);
+    run1<320, 2, false, true>("no DMA fragdb", A, W, sink);
+    run1<256, 2, true, true>("full fragdb", A, W, sink);
+    run1<256, 2, false, true>("no DMA fragdb", A, W, sink);
+    run1<128, 3, true, true>("full fragdb", A, W, sink);
+    run<320, 2, true, true, true, true, 3>("2 waves/SIMD noprio spread", A, W, sink);
+    run<256, 2, true, true, true, true, 3>("2 waves/SIMD noprio spread", A, W, sink);
+    run<128, 3, true, true, true, true, 3>("2 waves/SIMD noprio spread", A, W, sink);
+    if (getenv("UBENCH_FULL")) suite<320, 2>(A, W, sink);
+    if (getenv("UBENCH_FULL")) { suite<256, 2>(A, W, sink); suite<128, 3>(A, W, sink); }
     return 0;
 }
