@@ -218,6 +218,12 @@ def main():
         del video, rec
     clip_s = S * ms_per_step / 1e3 + ((enc_ms or 0) + (dec_ms or 0)) / 1e3
     fps = world * T / clip_s
+    guard = None
+    if os.environ.get("DC_ARENA_GUARD", "0") == "1":
+        # debugging aid: every scratch buffer sits between sentinel rows; raises if any launch wrote outside its buffer
+        n = model.model.diffusion_model._arena.check() + model.first_stage_model._arena.check()
+        guard = f"{n} scratch buffers verified"
+        log(f"arena guard: {guard}")
 
     out = {
         "metric": "frames/sec (and denoising-step ms), 16f@576x1024, DDIM 50" if res == "1024" else f"frames/sec, 16f @{res} config",
@@ -230,7 +236,7 @@ def main():
                    "clips_per_gpu": 1, "parallelism": f"dp{world} over clips (no data-path collective)",
                    "ae_encode_ms": None if enc_ms is None else round(enc_ms, 1),
                    "ae_decode_ms": None if dec_ms is None else round(dec_ms, 1),
-                   "clip_seconds": round(clip_s, 3), "outputs_finite": finite,
+                   "clip_seconds": round(clip_s, 3), "outputs_finite": finite, "scratch_guard": guard,
                    "step_ms_hip_events": round(ev_ms.value / args.steps, 3)},
     }
     if world == 1 and A100_REF.get(res):
