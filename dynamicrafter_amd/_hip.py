@@ -27,6 +27,7 @@ class DcGemmParams(C.Structure):
         ("stride", C.c_int), ("pad", C.c_int), ("ups", C.c_int),
         ("T", C.c_int), ("HW", C.c_int),
         ("flags", C.c_int), ("alpha", C.c_float),
+        ("workspace", C.c_void_p), ("workspace_bytes", C.c_longlong),
     ]
 
 
@@ -46,6 +47,7 @@ class DcDdimParams(C.Structure):
 _P, _I, _F, _L = C.c_void_p, C.c_int, C.c_float, C.c_int64
 SIGNATURES = {
     "dc_gemm_conv": (_I, [C.POINTER(DcGemmParams), _P]),
+    "dc_gemm_workspace_bytes": (_L, []),
     "dc_groupnorm": (_I, [_P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _F, _I, _P, _P]),
     "dc_groupnorm_workspace_bytes": (_L, [_I, _I, _I]),
     "dc_layernorm": (_I, [_P, _I, _P, _I, _P, _P, _I, _I, _F, _P]),

@@ -322,6 +322,11 @@ static bool glds_enabled() {
     return v == 1;
 }
 
+extern "C" int64_t dc_gemm_workspace_bytes(void) {
+    // split-K partials of the largest plan dispatched: 8 splits x 32 remainder tiles (or 3 x 72 tiles) of 256 x 320 fp32
+    return (int64_t)8 * 40 * 256 * 320 * 4;
+}
+
 extern "C" int dc_gemm_conv(const DcGemmParams* pp, void* stream_) {
     const DcGemmParams& p = *pp;
     hipStream_t stream = (hipStream_t)stream_;

@@ -53,8 +53,20 @@ __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
+// Split-K scheduling of a launch (host side: dc_gemm_conv_glds_try). A launch covers the logical tiles
+// [tile_begin, tile_begin + tile_count); with splits > 1, blockIdx.y selects a K range and the workgroup writes raw
+// fp32 accumulators to `partial` ([split][tile - tile_begin][256][BN]); splitk_reduce_kernel sums the splits in a
+// fixed order and applies the epilogue. Used where whole tiles cannot fill the chip: UNet level 3 (72 tiles of
+// 256 x 320) and the 32-tile remainder wave of level 2.
+struct GemmSplit {
+    float* partial;
+    int splits;
+    int tile_begin;
+    int tile_count;
+};
+
 template <int BN, bool GEGLU, int MODE, int GSTAGES>
-__global__ __launch_bounds__(GNT) void gemm_conv_glds_kernel(const DcGemmParams p) {
+__global__ __launch_bounds__(GNT) void gemm_conv_glds_kernel(const DcGemmParams p, const GemmSplit sp) {
     constexpr int NB = BN / 64;             // 32-wide n-blocks per wave (waves are 4 (M) x 2 (N))
     constexpr int BNOUT = GEGLU ? BN / 2 : BN;
     constexpr int A_BYTES = GBM * GBK * 2;
@@ -75,8 +87,7 @@ __global__ __launch_bounds__(GNT) void gemm_conv_glds_kernel(const DcGemmParams 
     const int n_out = GEGLU ? (p.N >> 1) : p.N;
     const int tiles_n = (n_out + BNOUT - 1) / BNOUT;
     const int tiles_m = (p.M + GBM - 1) / GBM;
-    const int nwg = tiles_m * tiles_n;
-    const int swz = xcd_remap(blockIdx.x, nwg);
+    const int swz = sp.tile_begin + xcd_remap(blockIdx.x, sp.tile_count);
     const int tile_n = swz % tiles_n;
     const int tile_m = swz / tiles_n;
     const int m0 = tile_m * GBM;
@@ -128,7 +139,10 @@ __global__ __launch_bounds__(GNT) void gemm_conv_glds_kernel(const DcGemmParams 
         b_ptr[j] = p.W + (size_t)wrow * p.K + chunk * 8;
     }
 
-    const int nk = p.K / GBK;
+    // this workgroup's K tiles: all of them, or the blockIdx.y-th of sp.splits near-equal ranges
+    const int nk_all = p.K / GBK;
+    const int kt_lo = (int)(((long long)blockIdx.y * nk_all) / sp.splits);
+    const int nk = (int)(((long long)(blockIdx.y + 1) * nk_all) / sp.splits);      // exclusive end
 
     // One quarter of a K tile's LDS-DMA: A instruction `part` and the B instructions j with j % 4 == part. The main
     // loop issues one quarter ahead of each 16-wide K step instead of the whole tile in one burst: a burst of
@@ -184,12 +198,12 @@ __global__ __launch_bounds__(GNT) void gemm_conv_glds_kernel(const DcGemmParams 
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    issue_tile(0, 0);
-    if (GSTAGES == 3 && nk > 1) issue_tile(1, 1);
+    issue_tile(kt_lo, 0);
+    if (GSTAGES == 3 && kt_lo + 1 < nk) issue_tile(kt_lo + 1, 1);
 
     const int fr = lane & 31, fh = lane >> 5;
     int stage = 0;
-    for (int kt = 0; kt < nk; ++kt) {
+    for (int kt = kt_lo; kt < nk; ++kt) {
         // tile kt has landed when at most the younger in-flight tile's LOADS remain outstanding
         if (GSTAGES == 3 && kt + 1 < nk) wait_vmcnt<LOADS>(); else wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();        // everyone's share of tile kt is in LDS; everyone is done with tile kt-1
@@ -266,6 +280,15 @@ __global__ __launch_bounds__(GNT) void gemm_conv_glds_kernel(const DcGemmParams 
             const int c = (u - r * UPR) * 4;
             const int m = m0 + (r >> 5) * 64 + mb * 32 + (r & 31);
             const int n = n0 + ws * PCOLS + c;
+            if constexpr (!GEGLU) {
+                if (sp.partial) {          // split-K: raw accumulators, tile-dense layout; the reduce kernel does the rest
+                    const float4 raw = *reinterpret_cast<const float4*>(cs + r * CS_LD + c * 4);
+                    const size_t slot = (size_t)blockIdx.y * sp.tile_count + (size_t)(swz - sp.tile_begin);
+                    const int rt = (r >> 5) * 64 + mb * 32 + (r & 31);
+                    *reinterpret_cast<float4*>(sp.partial + (slot * GBM + rt) * BN + ws * PCOLS + c) = raw;
+                    continue;
+                }
+            }
             if (m >= p.M || n >= n_out) continue;
             float4 v = *reinterpret_cast<const float4*>(cs + r * CS_LD + c * 4);
             if (p.bias) {
@@ -305,6 +328,51 @@ __global__ __launch_bounds__(GNT) void gemm_conv_glds_kernel(const DcGemmParams 
             }
         }
     }
+}
+
+// Sum of the split-K partials of the tiles [tile_begin, tile_begin + tile_count) in split order, then the same
+// epilogue as above (bias, GELU, per-row-group vector, alpha, bf16 rounding, residual). One thread per 4 channels.
+template <int BN>
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const DcGemmParams p, const GemmSplit sp) {
+    constexpr int UPR = BN / 4;
+    const int tiles_n = (p.N + BN - 1) / BN;
+    const int t_loc = blockIdx.y;
+    const int u = blockIdx.x * 256 + threadIdx.x;
+    if (u >= GBM * UPR) return;
+    const int r = u / UPR, c = (u - r * UPR) * 4;
+    const int tile = sp.tile_begin + t_loc;
+    const int m = (tile / tiles_n) * GBM + r, n = (tile % tiles_n) * BN + c;
+    if (m >= p.M || n >= p.N) return;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int s = 0; s < sp.splits; ++s) {
+        const float4 a = *reinterpret_cast<const float4*>(sp.partial + (((size_t)s * sp.tile_count + t_loc) * GBM + r) * BN + c);
+        v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
+    }
+    if (p.bias) {
+        const float4 bv = *reinterpret_cast<const float4*>(p.bias + n);
+        v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+    }
+    if (p.flags & DC_GEMM_GELU) { v.x = gelu_erf_f(v.x); v.y = gelu_erf_f(v.y); v.z = gelu_erf_f(v.z); v.w = gelu_erf_f(v.w); }
+    if (p.rowvec) {
+        const float4 rv = *reinterpret_cast<const float4*>(p.rowvec + (size_t)(m / p.rows_per_vec) * p.rowvec_ld + n);
+        v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
+    }
+    v.x *= p.alpha; v.y *= p.alpha; v.z *= p.alpha; v.w *= p.alpha;
+    if (p.flags & DC_GEMM_OUT_F32) {
+        *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.C) + (size_t)m * p.ldc + n) = v;
+        return;
+    }
+    uint2 pk;
+    pk.x = pack_bf2(v.x, v.y);
+    pk.y = pack_bf2(v.z, v.w);
+    if (p.residual) {
+        const uint2 rr = *reinterpret_cast<const uint2*>(p.residual + (size_t)m * p.ldr + n);
+        pk.x = pack_bf2(__uint_as_float(pk.x << 16) + __uint_as_float(rr.x << 16),
+                        __uint_as_float(pk.x & 0xffff0000u) + __uint_as_float(rr.x & 0xffff0000u));
+        pk.y = pack_bf2(__uint_as_float(pk.y << 16) + __uint_as_float(rr.y << 16),
+                        __uint_as_float(pk.y & 0xffff0000u) + __uint_as_float(rr.y & 0xffff0000u));
+    }
+    *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.C) + (size_t)m * p.ldc + n) = pk;
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -618,7 +686,36 @@ int launch_glds(const DcGemmParams& p, hipStream_t stream) {
         if (e != hipSuccess) return (int)e;
         configured = true;
     }
-    hipLaunchKernelGGL((gemm_conv_glds_kernel<BN, GEGLU, MODE, GSTAGES>), dim3(tiles_m * tiles_n), dim3(GNT), lds, stream, p);
+    GemmSplit sp;
+    sp.partial = nullptr; sp.splits = 1; sp.tile_begin = 0; sp.tile_count = tiles_m * tiles_n;
+    hipLaunchKernelGGL((gemm_conv_glds_kernel<BN, GEGLU, MODE, GSTAGES>), dim3(tiles_m * tiles_n), dim3(GNT), lds, stream, p, sp);
+    DC_CHECK_LAUNCH();
+    return 0;
+}
+
+// 320-wide tiles with split-K: `full` leading tiles as whole tiles (0 = none), the remaining tiles cut into `splits`
+// K ranges + reduce. Partials: splits * (ntiles - full) * 256 * 320 floats of workspace.
+template <int MODE>
+int launch_glds320_split(const DcGemmParams& p, hipStream_t stream, int ntiles, int full, int splits) {
+    constexpr int BN = 320, GSTAGES = 2;
+    constexpr size_t lds = (size_t)GSTAGES * (GBM * GBK * 2 + BN * GBK * 2);
+    static bool configured = false;
+    if (!configured) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_conv_glds_kernel<BN, false, MODE, GSTAGES>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+        configured = true;
+    }
+    GemmSplit sp;
+    if (full > 0) {
+        sp.partial = nullptr; sp.splits = 1; sp.tile_begin = 0; sp.tile_count = full;
+        hipLaunchKernelGGL((gemm_conv_glds_kernel<BN, false, MODE, GSTAGES>), dim3(full), dim3(GNT), lds, stream, p, sp);
+        DC_CHECK_LAUNCH();
+    }
+    sp.partial = reinterpret_cast<float*>(p.workspace); sp.splits = splits; sp.tile_begin = full; sp.tile_count = ntiles - full;
+    hipLaunchKernelGGL((gemm_conv_glds_kernel<BN, false, MODE, GSTAGES>), dim3(sp.tile_count, splits), dim3(GNT), lds, stream, p, sp);
+    DC_CHECK_LAUNCH();
+    hipLaunchKernelGGL((splitk_reduce_kernel<BN>), dim3((GBM * (BN / 4) + 255) / 256, sp.tile_count), dim3(256), 0, stream, p, sp);
     DC_CHECK_LAUNCH();
     return 0;
 }
@@ -692,6 +789,28 @@ int dc_gemm_conv_glds_try(const DcGemmParams& p, hipStream_t stream) {
     float s128 = wave_eff(w128) / waste128;
     if (w320 < 200) s320 = 0.f;
     if (w128 < 384) s128 = 0.f;
+    // split-K plans for the 320-wide tile (needs the caller's workspace)
+    static const int splitk = [] { const char* e = getenv("DC_GEMM_SPLITK"); return e ? atoi(e) : 1; }();
+    if (splitk && force == 0 && n320 && p.workspace && p.n_pad >= p.N) {
+        const int nk = p.K / GBK;
+        int full = 0, splits = 0;
+        if (w320 < 200 && w320 >= 32) {
+            // few tiles (UNet level 3): cut every tile so that tiles x splits just fills the chip
+            splits = 256 / w320;
+            if (splits > 8) splits = 8;
+        } else if (w320 > 256 && w320 <= 384 && wave_eff(w320 - 256) < 0.6f) {
+            // a little over one wave (level 2: 288 tiles): 256 whole tiles, then the remainder wave cut along K
+            full = 256;
+            splits = 256 / (w320 - 256);
+            if (splits > 8) splits = 8;
+        }
+        const size_t need = (size_t)splits * (size_t)(w320 - full) * GBM * 320 * sizeof(float);
+        if (splits >= 2 && nk / splits >= 12 && need <= (size_t)p.workspace_bytes) {
+            if (p.mode == 0) return launch_glds320_split<0>(p, stream, w320, full, splits);
+            if (p.mode == 1) return launch_glds320_split<1>(p, stream, w320, full, splits);
+            return launch_glds320_split<2>(p, stream, w320, full, splits);
+        }
+    }
     if (force == 320 && n320) return launch_glds_mode<320, 2>(p, stream);
     if (force == 128 && w128 > 0 && waste128 <= 1.15f) return launch_glds_mode<128, 3>(p, stream);
     if (force == 1) return -100;

@@ -179,6 +179,8 @@ def gemm(a, pw, out, *, M=None, residual=None, rowvec=None, rows_per_vec=1, gegl
     p.flags = (_hip.DC_GEMM_OUT_F32 if out_f32 else 0) | (_hip.DC_GEMM_GEGLU if geglu else 0) | \
         (_hip.DC_GEMM_GELU if gelu else 0)
     p.alpha = alpha
+    ws = _gemm_workspace(a.device)
+    p.workspace, p.workspace_bytes = ws.data_ptr(), ws.numel()
     if conv is not None:
         p.mode = 1
         p.IH, p.IW, p.OH, p.OW = conv["IH"], conv["IW"], conv["OH"], conv["OW"]
@@ -223,6 +225,18 @@ def gemm(a, pw, out, *, M=None, residual=None, rowvec=None, rows_per_vec=1, gegl
     else:
         check(_hip.lib().dc_gemm_conv(C.byref(p), stream_ptr()), "dc_gemm_conv")
     return out
+
+
+_gemm_ws = {}
+
+
+def _gemm_workspace(device):
+    """One scratch buffer per device for split-K partial sums (launches on one stream use it one after another)."""
+    buf = _gemm_ws.get(device.index)
+    if buf is None:
+        buf = torch.empty(int(_hip.lib().dc_gemm_workspace_bytes()), dtype=torch.uint8, device=device)
+        _gemm_ws[device.index] = buf
+    return buf
 
 
 class Arena:

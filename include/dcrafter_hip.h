@@ -49,7 +49,12 @@ typedef struct DcGemmParams {
     int T, HW;                /* mode 2: frames per clip, rows per frame */
     int flags;
     float alpha;              /* output scale applied last (before the residual add) */
+    void* workspace;          /* optional device scratch for split-K partial sums (dc_gemm_workspace_bytes()); NULL = never split */
+    long long workspace_bytes;
 } DcGemmParams;
+
+/* Recommended size of DcGemmParams.workspace (one buffer per stream; contents are scratch, no initialisation). */
+int64_t dc_gemm_workspace_bytes(void);
 
 /* Linear / 1x1 conv / conv2d 3x3 / Conv3d(3,1,1) on MFMA.
  * replaces: nn.Linear  lvdm/modules/attention.py:53-57,75-76,269,290,336,362,418,438

@@ -431,3 +431,40 @@ def test_gemm_geglu_ragged_wide(ops):
     h = x.float() @ bf(w).float().t() + b
     val, gate = h.chunk(2, dim=-1)
     assert rel_l2(out, val * F.gelu(gate)) < 4e-3
+
+
+# ---- split-K plans of the 320-wide tile: few tiles (level 3: every tile cut along K) and a little over one wave
+# (level 2: 256 whole tiles + the 32-tile remainder cut 8 ways), then the reduce kernel's epilogue
+@pytest.mark.parametrize("cfg,res", [
+    (dict(n=8, C=1280, Co=1280, H=18, W=32, stride=1, pad=1, ups=0), False),     # 18 x 4 = 72 tiles, 3 splits of 60 K tiles
+    (dict(n=8, C=1280, Co=1280, H=18, W=32, stride=1, pad=1, ups=0), True),
+    (dict(n=32, C=1280, Co=1280, H=18, W=32, stride=1, pad=1, ups=0), True),     # 288 tiles: 256 whole + 32 x 8 splits
+])
+def test_conv3x3_splitk(ops, cfg, res):
+    n, C, Co, H, W = (cfg[k] for k in ("n", "C", "Co", "H", "W"))
+    x = bf(rnd(n, C, H, W, seed=1)); w = rnd(Co, C, 3, 3, seed=2, scale=(9 * C) ** -0.5); b = rnd(Co, seed=3)
+    ref = F.conv2d(x.float(), bf(w).float(), b, padding=1).permute(0, 2, 3, 1).reshape(-1, Co)
+    r = bf(rnd(n * H * W, Co, seed=4)) if res else None
+    if res:
+        ref = bf(ref).float() + r.float()
+    pw = ops.PackedWeight.conv3x3(w, b, DEV)
+    rows = x.permute(0, 2, 3, 1).reshape(-1, C).contiguous().to(DEV)
+    outs = []
+    for _ in range(2):
+        out = torch.empty(n * H * W, Co, dtype=torch.bfloat16, device=DEV)
+        ops.gemm(rows, pw, out, conv=dict(IH=H, IW=W, OH=H, OW=W, stride=1, pad=1, ups=0),
+                 residual=None if r is None else r.to(DEV))
+        outs.append(out)
+    assert rel_l2(outs[0], ref) < 4e-3
+    assert torch.equal(outs[0], outs[1])                    # fixed summation order: bitwise reproducible
+
+
+def test_tconv3_splitk(ops):
+    B, T, HW, Cc = 2, 4, 576, 1280                          # M = 4608: 72 tiles, K = 3840 (60 K tiles) -> 3 splits
+    x = bf(rnd(B, Cc, T, HW, 1, seed=1)); w = rnd(Cc, Cc, 3, 1, 1, seed=2, scale=(3 * Cc) ** -0.5); b = rnd(Cc, seed=3)
+    ref = F.conv3d(x.float(), bf(w).float(), b, padding=(1, 0, 0))
+    pw = ops.PackedWeight.tconv3(w, b, DEV)
+    rows = x.permute(0, 2, 3, 4, 1).reshape(-1, Cc).contiguous().to(DEV)
+    out = torch.empty_like(rows)
+    ops.gemm(rows, pw, out, tconv=dict(T=T, HW=HW))
+    assert rel_l2(out, ref.permute(0, 2, 3, 4, 1).reshape(-1, Cc)) < 4e-3

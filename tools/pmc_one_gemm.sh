@@ -6,7 +6,7 @@ R=$GRAFT_REPO_ROOT
 name=$1; shift
 O=$R/gpurun_out/pmc_$name
 mkdir -p $O
-run() { n=$1; shift; rocprofv3 --kernel-trace --pmc "$@" -d $O/$n -o out --output-format csv -- python3 $R/tools/one_gemm.py $ARGS > $O/$n.log 2>&1 || { tail -5 $O/$n.log; return 1; }; }
+run() { n=$1; shift; rocprofv3 --kernel-trace --pmc "$@" -d $O/$n -o out --output-format csv -- python3 $R/tools/${PMC_SCRIPT:-one_gemm.py} $ARGS > $O/$n.log 2>&1 || { tail -5 $O/$n.log; return 1; }; }
 ARGS="$*"
 run sq1 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS && \
 run sq2 SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAIT_INST_LDS SQ_INSTS_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC && \

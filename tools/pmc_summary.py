@@ -7,11 +7,11 @@ for sub in sorted(os.listdir(d)):
         continue
     agg = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
-        if "gemm" in r["Kernel_Name"]:
+        if any(s in r["Kernel_Name"] for s in ("gemm", "flash", "gn_", "layernorm")):
             agg[(r["Kernel_Name"][:60], r["Counter_Name"])].append(float(r["Counter_Value"]))
     for (k, c), v in sorted(agg.items()):
         print(f"{sub:5s} {c:32s} n={len(v)} mean={sum(v) / len(v):.4g}   [{k}]")
     kt = os.path.join(d, sub, "out_kernel_trace.csv")
     if sub == "sq1" and os.path.exists(kt):
-        durs = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in csv.DictReader(open(kt)) if "gemm" in r["Kernel_Name"]]
+        durs = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in csv.DictReader(open(kt)) if any(s in r["Kernel_Name"] for s in ("gemm", "flash", "gn_", "layernorm"))]
         print("durations us:", " ".join(f"{x:.1f}" for x in durs))
