@@ -113,6 +113,24 @@ __global__ __launch_bounds__(GNT) void gemm_conv_glds_kernel(const DcGemmParams 
         if (MODE == 0) {
             if (ok) a_ptr[j] = p.A + (size_t)m * p.lda + chunk * 8;
         } else if (MODE == 1) {
+            // conv3x3 without upsampling: pointer to tap (0,0) of this output row (may lie outside the image: only
+            // dereferenced when its mask bit is set) + a 9-bit validity mask; the per-tap offset is wave-uniform
+            const int ohw = p.OH * p.OW;
+            const int mm = ok ? m : 0;
+            const int n = mm / ohw;
+            const int rem = mm - n * ohw;
+            const int oy = rem / p.OW;
+            const int ox = rem - oy * p.OW;
+            const int iy0 = oy * p.stride - p.pad, ix0 = ox * p.stride - p.pad;
+            int mask = 0;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int iy = iy0 + t / 3, ix = ix0 + t % 3;
+                if (ok && iy >= 0 && iy < p.IH && ix >= 0 && ix < p.IW) mask |= 1 << t;
+            }
+            a_base[j] = mask;
+            a_ptr[j] = p.A + ((long long)n * p.IH * p.IW + (long long)iy0 * p.IW + ix0) * p.lda + chunk * 8;
+        } else if (MODE == 3) {
             const int ohw = p.OH * p.OW;
             const int mm = ok ? m : 0;
             const int n = mm / ohw;
@@ -161,6 +179,12 @@ __global__ __launch_bounds__(GNT) void gemm_conv_glds_kernel(const DcGemmParams 
             } else if (MODE == 1) {
                 // K is ordered (64-channel slice, tap, channel): the 9 taps of one slice are consecutive K tiles, so
                 // taps 2..9 re-read (shifted) rows that the first tap just pulled into L2
+                const int cs = kt / 9;
+                const int tap = kt - cs * 9;
+                const int dy = tap / 3, dx = tap - dy * 3;
+                const long long toff = (long long)(dy * p.IW + dx) * p.lda + cs * 64;      // wave-uniform
+                src = ((a_base[j] >> tap) & 1) ? a_ptr[j] + toff : zero_ptr;
+            } else if (MODE == 3) {
                 const int cs = kt / 9;
                 const int tap = kt - cs * 9;
                 const int ci0 = cs * 64;
@@ -723,7 +747,7 @@ int launch_glds320_split(const DcGemmParams& p, hipStream_t stream, int ntiles, 
 template <int BN, int GSTAGES>
 int launch_glds_mode(const DcGemmParams& p, hipStream_t stream) {
     if (p.mode == 0) return launch_glds<BN, false, 0, GSTAGES>(p, stream);
-    if (p.mode == 1) return launch_glds<BN, false, 1, GSTAGES>(p, stream);
+    if (p.mode == 1) return p.ups ? launch_glds<BN, false, 3, GSTAGES>(p, stream) : launch_glds<BN, false, 1, GSTAGES>(p, stream);
     return launch_glds<BN, false, 2, GSTAGES>(p, stream);
 }
 
@@ -807,7 +831,8 @@ int dc_gemm_conv_glds_try(const DcGemmParams& p, hipStream_t stream) {
         const size_t need = (size_t)splits * (size_t)(w320 - full) * GBM * 320 * sizeof(float);
         if (splits >= 2 && nk / splits >= 12 && need <= (size_t)p.workspace_bytes) {
             if (p.mode == 0) return launch_glds320_split<0>(p, stream, w320, full, splits);
-            if (p.mode == 1) return launch_glds320_split<1>(p, stream, w320, full, splits);
+            if (p.mode == 1) return p.ups ? launch_glds320_split<3>(p, stream, w320, full, splits)
+                                          : launch_glds320_split<1>(p, stream, w320, full, splits);
             return launch_glds320_split<2>(p, stream, w320, full, splits);
         }
     }
