@@ -409,8 +409,11 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const DcGemmParams p
 // vmcnt bookkeeping: DMA is counted by hand (asm); the epilogue's loads/stores are compiler-counted. Retirement
 // is in issue order, and every compiler-visible operation is issued AFTER the DMA it could be confused with is
 // already older than the hand-counted window, so each counted wait can only over-wait, never under-wait.
-template <int BN, bool GEGLU, int GSTAGES, int EPI>
+// MODE as in gemm_conv_glds_kernel: 0 plain rows, 1 conv3x3 (no upsampling), 2 temporal 3-tap conv. The short-K convs
+// (level-0/1 ResBlock and TemporalConvBlock convs: 15-90 K tiles) gain from the same cross-tile pipelining.
+template <int BN, bool GEGLU, int GSTAGES, int EPI, int MODE>
 __global__ __launch_bounds__(GNT) void gemm_persist_kernel(const DcGemmParams p) {
+    static_assert(MODE == 0 || !GEGLU, "GEGLU is a plain-GEMM epilogue");
     constexpr int NB = BN / 64;
     constexpr int NBX = GEGLU ? NB / 2 : NB;
     constexpr int BNOUT = GEGLU ? BN / 2 : BN;
@@ -446,6 +449,7 @@ __global__ __launch_bounds__(GNT) void gemm_persist_kernel(const DcGemmParams p)
 
     // ---- issue side: descriptors of the tile whose K tiles are being requested
     const bf16_t* a_ptr[A_IT];
+    int a_aux[A_IT];            // MODE 1: 9-bit tap validity mask; MODE 2: frame index of the row (or -1000: row >= M)
     const bf16_t* b_ptr[B_IT];
     int i_tile = 0, i_kt = 0, i_stage = 0;
     auto set_issue_tile = [&](int j) __attribute__((always_inline)) {
@@ -457,7 +461,30 @@ __global__ __launch_bounds__(GNT) void gemm_persist_kernel(const DcGemmParams p)
             const int r = (q * 8 + wave) * 8 + srow;
             const int chunk = pchunk ^ ((r >> 1) & 7);
             const int m = m0 + r;
-            a_ptr[q] = (m < p.M) ? p.A + (size_t)m * p.lda + chunk * 8 : nullptr;
+            const bool ok = m < p.M;
+            a_aux[q] = 0;
+            if (MODE == 0) {
+                a_ptr[q] = ok ? p.A + (size_t)m * p.lda + chunk * 8 : nullptr;
+            } else if (MODE == 1) {
+                const int ohw = p.OH * p.OW;
+                const int mm = ok ? m : 0;
+                const int n = mm / ohw;
+                const int rem = mm - n * ohw;
+                const int oy = rem / p.OW;
+                const int ox = rem - oy * p.OW;
+                const int iy0 = oy * p.stride - p.pad, ix0 = ox * p.stride - p.pad;
+                int mask = 0;
+#pragma unroll
+                for (int t = 0; t < 9; ++t) {
+                    const int iy = iy0 + t / 3, ix = ix0 + t % 3;
+                    if (ok && iy >= 0 && iy < p.IH && ix >= 0 && ix < p.IW) mask |= 1 << t;
+                }
+                a_aux[q] = mask;
+                a_ptr[q] = p.A + ((long long)n * p.IH * p.IW + (long long)iy0 * p.IW + ix0) * p.lda + chunk * 8;
+            } else {
+                a_ptr[q] = p.A + (size_t)(ok ? m : 0) * p.lda + chunk * 8;
+                a_aux[q] = ok ? (m / p.HW) % p.T : -1000;
+            }
         }
 #pragma unroll
         for (int q = 0; q < B_IT; ++q) {
@@ -475,8 +502,26 @@ __global__ __launch_bounds__(GNT) void gemm_persist_kernel(const DcGemmParams p)
         const unsigned sa = lds_base + i_stage * STAGE;
         const unsigned sb = sa + A_BYTES;
 #pragma unroll
-        for (int q = 0; q < A_IT; ++q)
-            if (q == part) glds16(a_ptr[q] ? a_ptr[q] + k0 : zero_ptr, sa + (q * 8 + wave) * 1024);
+        for (int q = 0; q < A_IT; ++q) {
+            if (q != part) continue;
+            const bf16_t* src;
+            if (MODE == 0) {
+                src = a_ptr[q] ? a_ptr[q] + k0 : zero_ptr;
+            } else if (MODE == 1) {
+                const int cs = i_kt / 9;
+                const int tap = i_kt - cs * 9;
+                const int dy = tap / 3, dx = tap - dy * 3;
+                const long long toff = (long long)(dy * p.IW + dx) * p.lda + cs * 64;      // wave-uniform
+                src = ((a_aux[q] >> tap) & 1) ? a_ptr[q] + toff : zero_ptr;
+            } else {
+                const int cs = i_kt / 3;
+                const int tap = i_kt - cs * 3;
+                const long long shift = (long long)(tap - 1) * p.HW * p.lda + cs * 64;
+                const int tt = a_aux[q] + tap - 1;
+                src = (tt >= 0 && tt < p.T) ? a_ptr[q] + shift : zero_ptr;
+            }
+            glds16(src, sa + (q * 8 + wave) * 1024);
+        }
 #pragma unroll
         for (int q = 0; q < B_IT; ++q)
             if ((q & 3) == part) glds16(b_ptr[q] + k0, sb + (q * 8 + wave) * 1024);
@@ -666,7 +711,7 @@ __global__ __launch_bounds__(GNT) void gemm_persist_kernel(const DcGemmParams p)
     }
 }
 
-template <int BN, bool GEGLU, int EPI>
+template <int BN, bool GEGLU, int EPI, int MODE>
 int launch_persist_epi(const DcGemmParams& p, hipStream_t stream, int grid) {
     // ring depth by LDS budget (160 KB minus 8 x 2 KB of epilogue patches): 64-wide 3 x 40 KB, 128-wide 3 x 48 KB,
     // 256/320-wide 2 x 64/72 KB
@@ -675,12 +720,12 @@ int launch_persist_epi(const DcGemmParams& p, hipStream_t stream, int grid) {
     static_assert(lds <= 163840, "LDS budget");
     static bool configured = false;
     if (!configured) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_persist_kernel<BN, GEGLU, ST, EPI>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_persist_kernel<BN, GEGLU, ST, EPI, MODE>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
         configured = true;
     }
-    hipLaunchKernelGGL((gemm_persist_kernel<BN, GEGLU, ST, EPI>), dim3(grid), dim3(GNT), lds, stream, p);
+    hipLaunchKernelGGL((gemm_persist_kernel<BN, GEGLU, ST, EPI, MODE>), dim3(grid), dim3(GNT), lds, stream, p);
     DC_CHECK_LAUNCH();
     return 0;
 }
@@ -690,10 +735,18 @@ template <int BN, bool GEGLU>
 int launch_persist(const DcGemmParams& p, hipStream_t stream, int grid) {
     if (p.flags & DC_GEMM_OUT_F32) {
         if constexpr (GEGLU) return DC_ERR_ARG;
-        else return launch_persist_epi<BN, GEGLU, 2>(p, stream, grid);
+        else return launch_persist_epi<BN, GEGLU, 2, 0>(p, stream, grid);
     }
-    if (p.residual) return launch_persist_epi<BN, GEGLU, 1>(p, stream, grid);
-    return launch_persist_epi<BN, GEGLU, 0>(p, stream, grid);
+    if (p.residual) return launch_persist_epi<BN, GEGLU, 1, 0>(p, stream, grid);
+    return launch_persist_epi<BN, GEGLU, 0, 0>(p, stream, grid);
+}
+
+// 320-wide persistent conv3x3 (no upsampling) / temporal conv, bf16 outputs
+int launch_persist_conv320(const DcGemmParams& p, hipStream_t stream) {
+    if (p.mode == 1) return p.residual ? launch_persist_epi<320, false, 1, 1>(p, stream, 256)
+                                       : launch_persist_epi<320, false, 0, 1>(p, stream, 256);
+    return p.residual ? launch_persist_epi<320, false, 1, 2>(p, stream, 256)
+                      : launch_persist_epi<320, false, 0, 2>(p, stream, 256);
 }
 
 template <int BN, bool GEGLU, int MODE, int GSTAGES>
@@ -794,6 +847,10 @@ int dc_gemm_conv_glds_try(const DcGemmParams& p, hipStream_t stream) {
             if (waste > 1.15f && tiles_m * t64n >= 512) return launch_persist<64, false>(p, stream, 256);
         }
     }
+    static const int persist_conv_maxk = [] { const char* e = getenv("DC_GEMM_PERSIST_CONV_MAXK"); return e ? atoi(e) : 2880; }();
+    if (persist && force == 0 && !geglu && !out_f32 && epi16 && (p.mode == 2 || (p.mode == 1 && !p.ups)) &&
+        p.N % 320 == 0 && p.n_pad >= p.N && tiles_m * (p.N / 320) >= 512 && p.K <= persist_conv_maxk)
+        return launch_persist_conv320(p, stream);
     if (geglu) {
         const int w256 = (n_out % 128 == 0 && p.n_pad >= p.N) ? tiles_m * (n_out / 128) : 0;
         const int w128 = tiles_m * (n_out / 64);

@@ -468,3 +468,44 @@ def test_tconv3_splitk(ops):
     out = torch.empty_like(rows)
     ops.gemm(rows, pw, out, tconv=dict(T=T, HW=HW))
     assert rel_l2(out, ref.permute(0, 2, 3, 4, 1).reshape(-1, Cc)) < 4e-3
+
+
+# ---- persistent 256 x 320 kernel in conv / temporal-conv mode (>= 512 tiles, K <= 2880)
+@pytest.mark.parametrize("cfg", [
+    dict(n=16, C=128, Co=320, H=96, W=96, stride=1, pad=1, ups=0),        # 576 tiles, 18 K tiles
+    dict(n=15, C=64, Co=320, H=97, W=101, stride=1, pad=1, ups=0),        # ragged rows
+    dict(n=16, C=64, Co=320, H=192, W=192, stride=2, pad=1, ups=0),       # stride 2
+    dict(n=16, C=64, Co=320, H=192, W=192, stride=2, pad=0, ups=0),       # AE-style asymmetric pad
+])
+def test_conv3x3_persistent(ops, cfg):
+    test_conv3x3(ops, cfg)
+
+
+def test_conv3x3_persistent_residual_rowvec(ops):
+    n, C, Co, H, W = 16, 64, 640, 96, 96                   # 2 N tiles per row tile
+    x = bf(rnd(n, C, H, W, seed=1)); w = rnd(Co, C, 3, 3, seed=2, scale=(9 * C) ** -0.5); b = rnd(Co, seed=3)
+    emb = rnd(n // 4, Co, seed=5)                            # one vector per 4 frames
+    r = bf(rnd(n * H * W, Co, seed=4))
+    ref = F.conv2d(x.float(), bf(w).float(), b, padding=1).permute(0, 2, 3, 1).reshape(-1, Co)
+    ref = ref + emb.repeat_interleave(4 * H * W, 0)
+    ref = bf(ref).float() + r.float()
+    pw = ops.PackedWeight.conv3x3(w, b, DEV)
+    rows = x.permute(0, 2, 3, 1).reshape(-1, C).contiguous().to(DEV)
+    out = torch.empty(n * H * W, Co, dtype=torch.bfloat16, device=DEV)
+    ops.gemm(rows, pw, out, conv=dict(IH=H, IW=W, OH=H, OW=W, stride=1, pad=1, ups=0), residual=r.to(DEV),
+             rowvec=emb.to(DEV), rows_per_vec=4 * H * W)
+    assert rel_l2(out, ref) < 4e-3
+
+
+@pytest.mark.parametrize("B,T,HW", [(2, 16, 4608), (3, 5, 9830)])
+def test_tconv3_persistent(ops, B, T, HW):
+    Cc = 320
+    x = bf(rnd(B, Cc, T, HW, 1, seed=1)); w = rnd(Cc, Cc, 3, 1, 1, seed=2, scale=(3 * Cc) ** -0.5); b = rnd(Cc, seed=3)
+    ref = F.conv3d(x.float(), bf(w).float(), b, padding=(1, 0, 0))
+    pw = ops.PackedWeight.tconv3(w, b, DEV)
+    rows = x.permute(0, 2, 3, 4, 1).reshape(-1, Cc).contiguous().to(DEV)
+    r = bf(rnd(rows.shape[0], Cc, seed=4))
+    out = torch.empty_like(rows)
+    ops.gemm(rows, pw, out, tconv=dict(T=T, HW=HW), residual=r.to(DEV))
+    want = bf(ref.permute(0, 2, 3, 4, 1).reshape(-1, Cc)).float() + r.float()
+    assert rel_l2(out, want) < 4e-3
