@@ -39,13 +39,13 @@ __global__ void gn_partial_kernel(const bf16_t* __restrict__ x, int ldx, int C, 
     for (int e = 0; e < 8; ++e) { s[e] = 0.f; ss[e] = 0.f; }
     const bf16_t* base = x + (size_t)inst * rows_per_inst * ldx + v * 8;
     int r = r_begin + ro;
-    // four independent 16-byte loads in flight per lane (HBM latency, not issue rate, bounds this pass)
-    for (; r + 3 * rpp < r_end; r += 4 * rpp) {
-        uint4 raw[4];
+    // eight independent 16-byte loads in flight per lane (HBM latency, not issue rate, bounds this pass)
+    for (; r + 7 * rpp < r_end; r += 8 * rpp) {
+        uint4 raw[8];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) raw[u] = *reinterpret_cast<const uint4*>(base + (size_t)(r + u * rpp) * ldx);
+        for (int u = 0; u < 8; ++u) raw[u] = *reinterpret_cast<const uint4*>(base + (size_t)(r + u * rpp) * ldx);
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < 8; ++u) {
             float f[8];
             unpack_bf8(raw[u], f);
 #pragma unroll
@@ -80,28 +80,21 @@ __global__ void gn_partial_kernel(const bf16_t* __restrict__ x, int ldx, int C, 
     }
 }
 
-// grid n_inst, block 256: reduce chunks partials per group in a fixed order -> (mean, rstd)
-__global__ void gn_finalize_kernel(const float2* __restrict__ partial, int chunks, int groups, float count, float eps,
-                                   float2* __restrict__ stats) {
-    __shared__ float2 red[256];
-    const int inst = blockIdx.x;
-    const int g = threadIdx.x % groups;
-    const int part = threadIdx.x / groups;
-    const int nparts = 256 / groups;
+// grid (groups, n_inst), one wave each: reduce the chunk partials of one (instance, group) in a fixed order (lane-strided
+// sums, then a fixed shuffle tree) -> (mean, rstd). One workgroup per instance took 12 us on the 5-D norms (2 instances
+// x 1024 chunks); spread over groups it is launch-latency-bound.
+__global__ __launch_bounds__(64) void gn_finalize_kernel(const float2* __restrict__ partial, int chunks, int groups,
+                                                         float count, float eps, float2* __restrict__ stats) {
+    const int g = blockIdx.x, inst = blockIdx.y;
     float a = 0.f, b = 0.f;
-    if (part < nparts) {
-        for (int c = part; c < chunks; c += nparts) {
-            const float2 p = partial[((size_t)inst * chunks + c) * groups + g];
-            a += p.x; b += p.y;
-        }
+    for (int c = threadIdx.x; c < chunks; c += 64) {
+        const float2 p = partial[((size_t)inst * chunks + c) * groups + g];
+        a += p.x; b += p.y;
     }
-    red[threadIdx.x] = make_float2(a, b);
-    __syncthreads();
-    if ((int)threadIdx.x < groups) {
-        float sa = 0.f, sb = 0.f;
-        for (int q = 0; q < nparts; ++q) { sa += red[q * groups + g].x; sb += red[q * groups + g].y; }
-        const float mean = sa / count;
-        float var = sb / count - mean * mean;
+    a = wave_sum(a); b = wave_sum(b);
+    if (threadIdx.x == 0) {
+        const float mean = a / count;
+        float var = b / count - mean * mean;
         if (var < 0.f) var = 0.f;
         stats[(size_t)inst * groups + g] = make_float2(mean, rsqrtf(var + eps));
     }
@@ -130,12 +123,12 @@ __global__ void gn_apply_kernel(const bf16_t* __restrict__ x, int ldx, bf16_t* _
     const bf16_t* xb = x + (size_t)inst * rows_per_inst * ldx + v * 8;
     bf16_t* yb = y + (size_t)inst * rows_per_inst * ldy + v * 8;
     int r = r_begin + ro;
-    for (; r + 3 * rpp < r_end; r += 4 * rpp) {
-        uint4 raw[4];
+    for (; r + 7 * rpp < r_end; r += 8 * rpp) {
+        uint4 raw[8];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) raw[u] = *reinterpret_cast<const uint4*>(xb + (size_t)(r + u * rpp) * ldx);
+        for (int u = 0; u < 8; ++u) raw[u] = *reinterpret_cast<const uint4*>(xb + (size_t)(r + u * rpp) * ldx);
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < 8; ++u) {
             float f[8];
             unpack_bf8(raw[u], f);
 #pragma unroll
@@ -249,7 +242,7 @@ extern "C" int dc_groupnorm(const uint16_t* x, int ldx, uint16_t* y, int ldy, co
                        rows_per_inst, g.rows_per_chunk, g.chunks, vecs, rpp, partial);
     DC_CHECK_LAUNCH();
     const float count = (float)rows_per_inst * (float)(C / groups);
-    hipLaunchKernelGGL(gn_finalize_kernel, dim3(n_inst), dim3(256), 0, stream, partial, g.chunks, groups, count, eps,
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(groups, n_inst), dim3(64), 0, stream, partial, g.chunks, groups, count, eps,
                        stats);
     DC_CHECK_LAUNCH();
     hipLaunchKernelGGL(gn_apply_kernel, dim3(g.chunks, n_inst), dim3(threads), 0, stream, x, ldx, y, ldy, gamma, beta,
