@@ -190,3 +190,45 @@ def test_resampler_matches_reference(tag):
     sd = fill_state_dict(shapes, seed=14)
     y = ores.resampler_forward(sd, T(g["x"]), kw["heads"], kw["depth"])
     assert maxrel(y, g["y"]) < 2e-5
+
+
+@pytest.mark.parametrize("tag,cname", [("a", "512"), ("b", "256")])
+def test_harness_matches_reference(tag, cname):
+    """oracle/harness.py against scripts/evaluation/inference.py:image_guided_synthesis of the reference (toy CLIP
+    stand-ins -> Resampler -> conditioning assembly -> DDIM loop -> AE decode): 2-branch eta=1 with guidance rescale
+    (512 config) and interp + 3-branch guidance (256 config)."""
+    from oracle import harness as oh
+    from oracle import resampler  # noqa: F401
+    from tests.golden_cfg import TINY_AE, TINY_RESAMPLER, TINY_UNET, ToyImageEmbedder, ToyTextEmbedder
+    g = load(f"harness_{tag}")
+    kw = yaml.safe_load(str(g["kwargs"]))
+    extra = dict(image_cross_attention_scale_learnable=True) if cname == "256" else {}
+    ucfg = ounet.UNetCfg.from_params(dict(TINY_UNET, default_fs=24 if cname == "512" else 3, **extra))
+    usd = fill_state_dict(ounet.unet_param_shapes(ucfg), seed=11)
+    acfg = ovae.AECfg(ch=TINY_AE["ch"])
+    asd = fill_state_dict(ovae.ae_param_shapes(acfg), seed=13)
+    r = TINY_RESAMPLER
+    dim, inner, ffd = r["dim"], r["heads"] * r["dim_head"], int(r["dim"] * r["ff_mult"])
+    shapes = {"latents": (1, r["num_queries"] * r["video_length"], dim), "proj_in.weight": (dim, r["embedding_dim"]),
+              "proj_in.bias": (dim,), "proj_out.weight": (r["output_dim"], dim), "proj_out.bias": (r["output_dim"],),
+              "norm_out.weight": (r["output_dim"],), "norm_out.bias": (r["output_dim"],)}
+    for i in range(r["depth"]):
+        p = f"layers.{i}"
+        shapes.update({f"{p}.0.norm1.weight": (dim,), f"{p}.0.norm1.bias": (dim,), f"{p}.0.norm2.weight": (dim,),
+                       f"{p}.0.norm2.bias": (dim,), f"{p}.0.to_q.weight": (inner, dim),
+                       f"{p}.0.to_kv.weight": (2 * inner, dim), f"{p}.0.to_out.weight": (dim, inner),
+                       f"{p}.1.0.weight": (dim,), f"{p}.1.0.bias": (dim,), f"{p}.1.1.weight": (ffd, dim),
+                       f"{p}.1.3.weight": (dim, ffd)})
+    psd = fill_state_dict(shapes, seed=14)
+    videos = T(g["videos"])
+    ae_noise = T(g["ae_noise"])
+    # the reference draws ONE posterior noise tensor per encode call: per frame when perframe_ae (512 config), one
+    # [1,4,h,w] draw broadcast over the 4-frame batch otherwise (256 config) - see make_golden.gen_harness
+    noise = ae_noise if cname == "512" else ae_noise[:1].expand(videos.shape[2], -1, -1, -1)
+    out = oh.image_guided_synthesis(
+        unet_sd=usd, unet_cfg=ucfg, ae_sd=asd, ae_cfg=acfg, proj_sd=psd, proj_heads=r["heads"], proj_depth=r["depth"],
+        embed_image=ToyImageEmbedder(), embed_text=ToyTextEmbedder().encode, schedule=_ms_for(cname), scale_factor=0.18215,
+        uncond_type="empty_seq", prompts=["a corgi running on the beach"], videos=videos, x_T=T(g["x_T"]),
+        noises=T(g["noises"]), ae_noise=noise, **kw)
+    assert tuple(out.shape) == tuple(g["out"].shape)
+    assert maxrel(out, g["out"]) < 5e-4
