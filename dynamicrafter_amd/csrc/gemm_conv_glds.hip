@@ -875,10 +875,11 @@ int dc_gemm_conv_glds_try(const DcGemmParams& p, hipStream_t stream) {
     if (splitk && force == 0 && n320 && p.workspace && p.n_pad >= p.N) {
         const int nk = p.K / GBK;
         int full = 0, splits = 0;
-        if (w320 < 200 && w320 >= 32) {
+        if (w320 < 200 && w320 >= 8) {
             // few tiles (UNet level 3): cut every tile so that tiles x splits just fills the chip
             splits = 256 / w320;
-            if (splits > 8) splits = 8;
+            if (splits > 12) splits = 12;
+            while (splits > 2 && nk / splits < 12) --splits;
         } else if (w320 > 256 && w320 <= 384 && wave_eff(w320 - 256) < 0.6f) {
             // a little over one wave (level 2: 288 tiles): 256 whole tiles, then the remainder wave cut along K
             full = 256;
