@@ -48,6 +48,7 @@ _P, _I, _F, _L = C.c_void_p, C.c_int, C.c_float, C.c_int64
 SIGNATURES = {
     "dc_gemm_conv": (_I, [C.POINTER(DcGemmParams), _P]),
     "dc_gemm_workspace_bytes": (_L, []),
+    "dc_gemm_last_variant": (C.c_char_p, []),
     "dc_groupnorm": (_I, [_P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _F, _I, _P, _P]),
     "dc_groupnorm_workspace_bytes": (_L, [_I, _I, _I]),
     "dc_layernorm": (_I, [_P, _I, _P, _I, _P, _P, _I, _I, _F, _P]),

@@ -85,4 +85,7 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     return base + idx;
 }
 
+// which kernel family dc_gemm_conv's dispatcher launched last on this host thread (profiling label; gemm_conv.hip)
+void dc_note_variant(const char* name);
+
 #define DC_CHECK_LAUNCH() do { hipError_t e__ = hipGetLastError(); if (e__ != hipSuccess) return (int)e__; } while (0)

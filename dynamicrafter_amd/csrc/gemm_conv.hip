@@ -295,6 +295,7 @@ int launch_mode(const DcGemmParams& p, hipStream_t stream) {
     const int tiles_n = (n_out + BNOUT - 1) / BNOUT;
     const int tiles_m = (p.M + BM - 1) / BM;
     const size_t lds = 2 * (BM * BK * 2 + BN * BK * 2);
+    dc_note_variant(GEGLU ? "gemm_conv_kernel<geglu>" : (BN == 64 ? "gemm_conv_kernel<64>" : "gemm_conv_kernel<128>"));
     hipLaunchKernelGGL((gemm_conv_kernel<BN, GEGLU, MODE>), dim3(tiles_m * tiles_n), dim3(NTHREADS), lds, stream, p);
     DC_CHECK_LAUNCH();
     return 0;
@@ -321,6 +322,10 @@ static bool glds_enabled() {
     }
     return v == 1;
 }
+
+static thread_local const char* g_last_variant = "none";
+void dc_note_variant(const char* name) { g_last_variant = name; }
+extern "C" const char* dc_gemm_last_variant(void) { return g_last_variant; }
 
 extern "C" int64_t dc_gemm_workspace_bytes(void) {
     // split-K partials of the largest plan dispatched: 8 splits x 32 remainder tiles (or 3 x 72 tiles) of 256 x 320 fp32

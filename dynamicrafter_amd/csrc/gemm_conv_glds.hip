@@ -725,6 +725,10 @@ int launch_persist_epi(const DcGemmParams& p, hipStream_t stream, int grid) {
         if (e != hipSuccess) return (int)e;
         configured = true;
     }
+    dc_note_variant(GEGLU ? (BN == 256 ? "gemm_persist_kernel<256,geglu>" : "gemm_persist_kernel<128,geglu>")
+                    : MODE == 1 ? "gemm_persist_kernel<320,conv>" : MODE == 2 ? "gemm_persist_kernel<320,tconv>"
+                    : BN == 320 ? (EPI == 1 ? "gemm_persist_kernel<320,residual>" : "gemm_persist_kernel<320>")
+                    : BN == 128 ? "gemm_persist_kernel<128>" : "gemm_persist_kernel<64>");
     hipLaunchKernelGGL((gemm_persist_kernel<BN, GEGLU, ST, EPI, MODE>), dim3(grid), dim3(GNT), lds, stream, p);
     DC_CHECK_LAUNCH();
     return 0;
@@ -765,6 +769,9 @@ int launch_glds(const DcGemmParams& p, hipStream_t stream) {
     }
     GemmSplit sp;
     sp.partial = nullptr; sp.splits = 1; sp.tile_begin = 0; sp.tile_count = tiles_m * tiles_n;
+    dc_note_variant(GEGLU ? "gemm_conv_glds_kernel<geglu>"
+                    : BN == 320 ? (MODE == 0 ? "gemm_conv_glds_kernel<320>" : MODE == 2 ? "gemm_conv_glds_kernel<320,tconv>" : "gemm_conv_glds_kernel<320,conv>")
+                    : (MODE == 0 ? "gemm_conv_glds_kernel<128>" : MODE == 2 ? "gemm_conv_glds_kernel<128,tconv>" : "gemm_conv_glds_kernel<128,conv>"));
     hipLaunchKernelGGL((gemm_conv_glds_kernel<BN, GEGLU, MODE, GSTAGES>), dim3(tiles_m * tiles_n), dim3(GNT), lds, stream, p, sp);
     DC_CHECK_LAUNCH();
     return 0;
@@ -783,6 +790,7 @@ int launch_glds320_split(const DcGemmParams& p, hipStream_t stream, int ntiles, 
         if (e != hipSuccess) return (int)e;
         configured = true;
     }
+    dc_note_variant(MODE == 0 ? "gemm_conv_glds_kernel<320>+splitk" : MODE == 2 ? "gemm_conv_glds_kernel<320,tconv>+splitk" : "gemm_conv_glds_kernel<320,conv>+splitk");
     GemmSplit sp;
     if (full > 0) {
         sp.partial = nullptr; sp.splits = 1; sp.tile_begin = 0; sp.tile_count = full;
@@ -880,14 +888,16 @@ int dc_gemm_conv_glds_try(const DcGemmParams& p, hipStream_t stream) {
             splits = 256 / w320;
             if (splits > 12) splits = 12;
             while (splits > 2 && nk / splits < 12) --splits;
-        } else if (w320 > 256 && w320 <= 384 && wave_eff(w320 - 256) < 0.6f) {
-            // a little over one wave (level 2: 288 tiles): 256 whole tiles, then the remainder wave cut along K
-            full = 256;
-            splits = 256 / (w320 - 256);
+        } else if (w320 > 256 && w320 <= 1280 && (w320 % 256) != 0 && (w320 % 256) <= 128) {
+            // whole waves of 256 tiles, then the partial last wave cut along K so that it fills the chip
+            // (level 2: 288 = 256 + 32 x 8; level 1, N = 640: 576 = 512 + 64 x 4)
+            full = (w320 / 256) * 256;
+            splits = 256 / (w320 - full);
             if (splits > 8) splits = 8;
+            while (splits > 2 && nk / splits < 8) --splits;
         }
         const size_t need = (size_t)splits * (size_t)(w320 - full) * GBM * 320 * sizeof(float);
-        if (splits >= 2 && nk / splits >= 12 && need <= (size_t)p.workspace_bytes) {
+        if (splits >= 2 && nk / splits >= (full ? 8 : 12) && need <= (size_t)p.workspace_bytes) {
             if (p.mode == 0) return launch_glds320_split<0>(p, stream, w320, full, splits);
             if (p.mode == 1) return p.ups ? launch_glds320_split<3>(p, stream, w320, full, splits)
                                           : launch_glds320_split<1>(p, stream, w320, full, splits);

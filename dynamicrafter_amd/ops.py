@@ -73,6 +73,8 @@ def _launch(name, flops, nbytes, fn, *args, tag=None):
     l.dc_event_record(e0, sp)
     check(fn(*args), name)
     l.dc_event_record(e1, sp)
+    if name == "dc_gemm_conv":                      # label by the kernel family the dispatcher actually launched
+        name = l.dc_gemm_last_variant().decode()
     tr.records.append((name, flops, nbytes, e0, e1, tag))
 
 
@@ -213,8 +215,7 @@ def gemm(a, pw, out, *, M=None, residual=None, rowvec=None, rows_per_vec=1, gegl
     if rowvec is not None and (rowvec.shape[0] * rows_per_vec < p.M or rowvec.shape[1] < n_out):
         raise ValueError("gemm: rowvec does not cover every row group / output column")
     if _TRACE is not None:
-        t128 = (pw.N + 127) // 128 * 128
-        variant = "gemm_conv<128,geglu>" if geglu else ("gemm_conv<64>" if (pw.N <= 64 or t128 / pw.N > 1.15) else "gemm_conv<128>")
+        variant = "dc_gemm_conv"
         k_real = pw.k_real if pw.k_real else pw.K
         flops = 2.0 * p.M * pw.N * k_real
         esz = 4 if out_f32 else 2

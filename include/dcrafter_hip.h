@@ -53,6 +53,9 @@ typedef struct DcGemmParams {
     long long workspace_bytes;
 } DcGemmParams;
 
+/* Name of the kernel family the last dc_gemm_conv call of this host thread dispatched to (profiling label). */
+const char* dc_gemm_last_variant(void);
+
 /* Recommended size of DcGemmParams.workspace (one buffer per stream; contents are scratch, no initialisation). */
 int64_t dc_gemm_workspace_bytes(void);
 
