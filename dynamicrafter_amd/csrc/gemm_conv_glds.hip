@@ -771,6 +771,7 @@ int launch_glds(const DcGemmParams& p, hipStream_t stream) {
     sp.partial = nullptr; sp.splits = 1; sp.tile_begin = 0; sp.tile_count = tiles_m * tiles_n;
     dc_note_variant(GEGLU ? "gemm_conv_glds_kernel<geglu>"
                     : BN == 320 ? (MODE == 0 ? "gemm_conv_glds_kernel<320>" : MODE == 2 ? "gemm_conv_glds_kernel<320,tconv>" : "gemm_conv_glds_kernel<320,conv>")
+                    : BN == 256 ? (MODE == 0 ? "gemm_conv_glds_kernel<256>" : MODE == 2 ? "gemm_conv_glds_kernel<256,tconv>" : "gemm_conv_glds_kernel<256,conv>")
                     : (MODE == 0 ? "gemm_conv_glds_kernel<128>" : MODE == 2 ? "gemm_conv_glds_kernel<128,tconv>" : "gemm_conv_glds_kernel<128,conv>"));
     hipLaunchKernelGGL((gemm_conv_glds_kernel<BN, GEGLU, MODE, GSTAGES>), dim3(tiles_m * tiles_n), dim3(GNT), lds, stream, p, sp);
     DC_CHECK_LAUNCH();
@@ -907,6 +908,9 @@ int dc_gemm_conv_glds_try(const DcGemmParams& p, hipStream_t stream) {
     if (force == 320 && n320) return launch_glds_mode<320, 2>(p, stream);
     if (force == 128 && w128 > 0 && waste128 <= 1.15f) return launch_glds_mode<128, 3>(p, stream);
     if (force == 1) return -100;
+    // 256-wide plain tile for the AutoencoderKL widths (N = 256 / 512: not multiples of 320)
+    const int w256 = (!n320 && p.N % 256 == 0 && p.n_pad >= p.N) ? tiles_m * (p.N / 256) : 0;
+    if ((force == 256 || force == 0) && w256 >= 200 && 1.2f * wave_eff(w256) >= s128) return launch_glds_mode<256, 2>(p, stream);
     if (s320 > 0.f && s320 >= s128) return launch_glds_mode<320, 2>(p, stream);
     if (s128 > 0.f && waste128 <= 1.15f) return launch_glds_mode<128, 3>(p, stream);
     return -100;
