@@ -61,8 +61,16 @@ __global__ __launch_bounds__(256, 2) void flash_attn_d64_kernel(
         qrow[x] = qt * (FA_BQ * QB) + (wave * QB + x) * 32 + fr;
         const int qc = qrow[x] < Lq ? qrow[x] : Lq - 1;
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk)
-            qf[x][kk] = *reinterpret_cast<const bf16x8_t*>(qb + (size_t)qc * ldq + kk * 16 + fh * 8);
+        for (int kk = 0; kk < 4; ++kk) {
+            // Q is pre-multiplied by scale*log2(e) (one extra bf16 rounding of Q, the size of the one it already has):
+            // the scores then leave the MFMA in exp2 units and, with the accumulator started at -m, as s - m directly
+            const u32x4_t raw = *reinterpret_cast<const u32x4_t*>(qb + (size_t)qc * ldq + kk * 16 + fh * 8);
+            u32x4_t sc;
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                sc[e] = pack_bf2(__uint_as_float(raw[e] << 16) * c, __uint_as_float(raw[e] & 0xffff0000u) * c);
+            qf[x][kk] = __builtin_bit_cast(bf16x8_t, sc);
+        }
     }
 
     // ---- staging coordinates: 64 rows x 8 chunks per tensor, 2 rows per thread
@@ -91,10 +99,10 @@ __global__ __launch_bounds__(256, 2) void flash_attn_d64_kernel(
     };
 
     f32x16_t oacc[QB][2];
-    float m_run[QB], l_run[QB];
+    float m_run[QB], l_run[QB];       // m_run: running row max in exp2 units (0 until the first tile sets it)
 #pragma unroll
     for (int x = 0; x < QB; ++x) {
-        m_run[x] = -1e30f; l_run[x] = 0.f;
+        m_run[x] = 0.f; l_run[x] = 0.f;
 #pragma unroll
         for (int d = 0; d < 2; ++d)
 #pragma unroll
@@ -117,14 +125,15 @@ __global__ __launch_bounds__(256, 2) void flash_attn_d64_kernel(
         const char* sk = smem + buf * FA_STAGE;
         const char* sv = sk + FA_KBYTES;
 
-        // S^T[x][jb] = K[jb] Q[x]^T  — every K fragment is read once and used for all QB query blocks
+        // S^T[x][jb] = K[jb] (c Q[x])^T - m[x]: the accumulators start at minus the running max of the earlier tiles, so
+        // the common case needs no per-score subtraction. Every K fragment is read once for all QB query blocks.
         f32x16_t s[QB][2];
 #pragma unroll
         for (int x = 0; x < QB; ++x)
 #pragma unroll
             for (int jb = 0; jb < 2; ++jb)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) s[x][jb][r] = 0.f;
+                for (int r = 0; r < 16; ++r) s[x][jb][r] = -m_run[x];
 #pragma unroll
         for (int jb = 0; jb < 2; ++jb)
 #pragma unroll
@@ -156,24 +165,29 @@ __global__ __launch_bounds__(256, 2) void flash_attn_d64_kernel(
 #pragma unroll
             for (int r = 0; r < 16; r += 2) mx = fmaxf(fmaxf(mx, s[x][1][r]), s[x][1][r + 1]);
             mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-            // rescale only when some row's running max actually grew (alpha == 1 exactly otherwise: skipping is exact)
-            if (__any(mx > m_run[x])) {
-                const float m_new = fmaxf(m_run[x], mx);
-                const float alpha = __builtin_amdgcn_exp2f((m_run[x] - m_new) * c);
-                m_run[x] = m_new;
+            // mx = (tile max) - m_run. The running max moves only when some row's grew (or on the first tile, where
+            // it is simply set): then the scores are shifted by the step and the running state rescaled. Otherwise
+            // the step is 0 and alpha 1 exactly, so skipping the block is exact.
+            if (t == 0 || __any(mx > 0.f)) {
+                const float step = (t == 0) ? mx : fmaxf(mx, 0.f);
+                const float alpha = __builtin_amdgcn_exp2f(-step);
+                m_run[x] += step;
                 l_run[x] *= alpha;
 #pragma unroll
                 for (int d = 0; d < 2; ++d)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) oacc[x][d][r] *= alpha;
+#pragma unroll
+                for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) s[x][jb][r] -= step;
             }
-            const float mc = m_run[x] * c;
             float psum = 0.f;
 #pragma unroll
             for (int jb = 0; jb < 2; ++jb)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const float p = __builtin_amdgcn_exp2f(fmaf(s[x][jb][r], c, -mc));
+                    const float p = __builtin_amdgcn_exp2f(s[x][jb][r]);
                     s[x][jb][r] = p;
                     psum += p;
                 }
