@@ -8,7 +8,8 @@ import os
 import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libdcrafter_hip.so")
+# DC_HIP_LIB: load an alternative build of the same library (instrumented tool builds, tools/gemm_stamps.py)
+LIB_PATH = os.environ.get("DC_HIP_LIB") or os.path.join(_HERE, "csrc", "libdcrafter_hip.so")
 
 DC_GEMM_OUT_F32 = 1
 DC_GEMM_GEGLU = 2

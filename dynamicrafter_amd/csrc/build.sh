@@ -3,15 +3,16 @@
 set -euo pipefail
 HERE="$(cd "$(dirname "$0")" && pwd)"
 ROOT="$(cd "$HERE/../.." && pwd)"
-OUT="$HERE/libdcrafter_hip.so"
+OUT="${DC_OUT:-$HERE/libdcrafter_hip.so}"      # DC_OUT / DC_EXTRA_FLAGS: instrumented tool builds (tools/gemm_stamps.py)
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
-FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -I$ROOT/include -I$HERE"
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -I$ROOT/include -I$HERE ${DC_EXTRA_FLAGS:-}"
+OBJDIR="${DC_OBJDIR:-$HERE}"
 OBJS=()
 pids=()
 for f in gemm_conv gemm_conv_glds norms attention elementwise runtime; do
-  "$HIPCC" $FLAGS -c "$HERE/$f.hip" -o "$HERE/$f.o" &
+  "$HIPCC" $FLAGS -c "$HERE/$f.hip" -o "$OBJDIR/$f.o" &
   pids+=($!)
-  OBJS+=("$HERE/$f.o")
+  OBJS+=("$OBJDIR/$f.o")
 done
 for p in "${pids[@]}"; do wait "$p"; done
 "$HIPCC" --offload-arch=gfx950 -shared -fPIC -o "$OUT" "${OBJS[@]}"

@@ -227,18 +227,38 @@ __global__ __launch_bounds__(GNT) void gemm_conv_glds_kernel(const DcGemmParams 
 
     const int fr = lane & 31, fh = lane >> 5;
     int stage = 0;
+#ifdef DC_GEMM_STAMPS
+    // tool build only (tools/gemm_stamps.py): shader-clock time per wave spent in the vmcnt wait, at the barrier and in
+    // the K-step body (DMA issue + fragment reads + MFMA), summed over the K loop
+    unsigned long long st_vm = 0, st_bar = 0, st_body = 0;
+    unsigned long long st_t = __builtin_readcyclecounter();
+#endif
     for (int kt = kt_lo; kt < nk; ++kt) {
         // tile kt has landed when at most the younger in-flight tile's LOADS remain outstanding
         if (GSTAGES == 3 && kt + 1 < nk) wait_vmcnt<LOADS>(); else wait_vmcnt<0>();
+#ifdef DC_GEMM_STAMPS
+        { const unsigned long long t = __builtin_readcyclecounter(); st_vm += t - st_t; st_t = t; }
+#endif
         __builtin_amdgcn_s_barrier();        // everyone's share of tile kt is in LDS; everyone is done with tile kt-1
         asm volatile("" ::: "memory");
+#ifdef DC_GEMM_STAMPS
+        { const unsigned long long t = __builtin_readcyclecounter(); st_bar += t - st_t; st_t = t; }
+#endif
         const bool more = kt + GSTAGES - 1 < nk;
         int s2 = stage + GSTAGES - 1; if (s2 >= GSTAGES) s2 -= GSTAGES;
         const char* sa = smem + stage * STAGE;
         const char* sb = sa + A_BYTES;
 #pragma unroll
         for (int kk = 0; kk < GBK / 16; ++kk) {
+            // a quarter of the next K tile's LDS-DMA ahead of every K step (DC_GLDS_ISSUE=1: one burst, =2: two halves ahead
+            // of steps 0 and 1 - tool builds; same-box A/B of the whole step: 155.0 (halves) vs 154.6 ms (quarters))
+#if defined(DC_GLDS_ISSUE) && DC_GLDS_ISSUE == 1
+            if (more && kk == 0) issue_tile(kt + GSTAGES - 1, s2);
+#elif defined(DC_GLDS_ISSUE) && DC_GLDS_ISSUE == 2
+            if (more && kk < 2) { issue_part(kt + GSTAGES - 1, s2, 2 * kk); issue_part(kt + GSTAGES - 1, s2, 2 * kk + 1); }
+#else
             if (more) issue_part(kt + GSTAGES - 1, s2, kk);
+#endif
             bf16x8_t xf[2], wf[NB];
 #pragma unroll
             for (int mb = 0; mb < 2; ++mb)
@@ -257,9 +277,18 @@ __global__ __launch_bounds__(GNT) void gemm_conv_glds_kernel(const DcGemmParams 
                     acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[nb], xf[mb], acc[mb][nb], 0, 0, 0);
         }
         ++stage; if (stage >= GSTAGES) stage = 0;
+#ifdef DC_GEMM_STAMPS
+        { const unsigned long long t = __builtin_readcyclecounter(); st_body += t - st_t; st_t = t; }
+#endif
     }
     wait_vmcnt<0>();
     __syncthreads();                         // all fragment reads done before the ring is reused for the epilogue
+#ifdef DC_GEMM_STAMPS
+    if (lane == 0 && p.workspace && !sp.partial && (size_t)(blockIdx.x * 8 + wave + 1) * 32 <= (size_t)p.workspace_bytes) {
+        unsigned long long* out = reinterpret_cast<unsigned long long*>(p.workspace) + (size_t)(blockIdx.x * 8 + wave) * 4;
+        out[0] = st_vm; out[1] = st_bar; out[2] = st_body; out[3] = (unsigned long long)(nk - kt_lo);
+    }
+#endif
 
     // ---------------- epilogue: fp32 through LDS, four passes (mb x wave column), coalesced row-major read-back.
     // Pass (mb, ws): the four waves with wn == ws stage acc[mb][*] for their 128 rows; then every thread reads back
