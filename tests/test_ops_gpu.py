@@ -509,3 +509,55 @@ def test_tconv3_persistent(ops, B, T, HW):
     ops.gemm(rows, pw, out, tconv=dict(T=T, HW=HW), residual=r.to(DEV))
     want = bf(ref.permute(0, 2, 3, 4, 1).reshape(-1, Cc)).float() + r.float()
     assert rel_l2(out, want) < 4e-3
+
+
+# ---- dispatch fuzz: random shapes across the tile / persistent / split-K decision boundaries. The checker is a
+# device-side fp32 matmul / conv (rocBLAS / MIOpen via torch) - CPU references of these sizes would take minutes.
+def _fuzz_cases():
+    import random
+    rng = random.Random(1234)
+    Ns = [64, 128, 256, 320, 512, 640, 960, 1280, 1920, 2560]
+    cases = []
+    for i in range(28):
+        N = rng.choice(Ns)
+        K = 64 * rng.choice([1, 2, 5, 8, 10, 20, 30, 40, 60])
+        M = rng.choice([rng.randint(1, 4000), rng.randint(4000, 40000), rng.randint(40000, 160000)])
+        cases.append((M, N, K, rng.random() < 0.4, rng.random() < 0.8, i))
+    return cases
+
+
+@pytest.mark.parametrize("M,N,K,res,bias,seed", _fuzz_cases())
+def test_gemm_dispatch_fuzz(ops, M, N, K, res, bias, seed):
+    g = torch.Generator(device=DEV).manual_seed(seed)
+    x = torch.randn(M, K, device=DEV, generator=g).to(torch.bfloat16)
+    w = (torch.randn(N, K, device=DEV, generator=g) * K ** -0.5)
+    b = torch.randn(N, device=DEV, generator=g) if bias else None
+    r = torch.randn(M, N, device=DEV, generator=g).to(torch.bfloat16) if res else None
+    pw = ops.PackedWeight.linear(w.cpu(), None if b is None else b.cpu(), DEV)
+    out = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+    ops.gemm(x, pw, out, residual=r)
+    ref = x.float() @ w.to(torch.bfloat16).float().t()
+    if b is not None:
+        ref = ref + b
+    if r is not None:
+        ref = ref.to(torch.bfloat16).float() + r.float()
+    assert rel_l2(out, ref) < 4e-3, ops._hip.lib().dc_gemm_last_variant().decode()
+
+
+@pytest.mark.parametrize("n,C,Co,H,W,stride,seed", [
+    (5, 64, 320, 40, 64, 1, 0), (32, 320, 320, 40, 64, 1, 1), (32, 640, 640, 20, 32, 1, 2), (32, 1280, 1280, 10, 16, 1, 3),
+    (32, 1280, 1280, 5, 8, 1, 4), (32, 320, 320, 40, 64, 2, 5), (32, 640, 1280, 20, 32, 1, 6), (7, 1920, 640, 23, 31, 1, 7),
+    (2, 2560, 1280, 18, 32, 1, 8), (33, 960, 320, 17, 29, 1, 9)])
+def test_conv_dispatch_fuzz(ops, n, C, Co, H, W, stride, seed):
+    g = torch.Generator(device=DEV).manual_seed(seed)
+    x = torch.randn(n, C, H, W, device=DEV, generator=g).to(torch.bfloat16)
+    w = torch.randn(Co, C, 3, 3, device=DEV, generator=g) * (9 * C) ** -0.5
+    b = torch.randn(Co, device=DEV, generator=g)
+    ref = F.conv2d(x.float(), w.to(torch.bfloat16).float(), b, stride=stride, padding=1)
+    OH, OW = ref.shape[2], ref.shape[3]
+    pw = ops.PackedWeight.conv3x3(w.cpu(), b.cpu(), DEV)
+    rows = x.permute(0, 2, 3, 1).reshape(-1, C).contiguous()
+    out = torch.empty(n * OH * OW, Co, dtype=torch.bfloat16, device=DEV)
+    ops.gemm(rows, pw, out, conv=dict(IH=H, IW=W, OH=OH, OW=OW, stride=stride, pad=1, ups=0))
+    want = ref.permute(0, 2, 3, 1).reshape(-1, Co)
+    assert rel_l2(out, want) < 4e-3, ops._hip.lib().dc_gemm_last_variant().decode()
