@@ -843,7 +843,7 @@ int launch_glds_mode(const DcGemmParams& p, hipStream_t stream) {
 }
 
 inline int persist_max_k() {
-    static const int v = [] { const char* e = getenv("DC_GEMM_PERSIST_MAXK"); return e ? atoi(e) : 1280; }();
+    static const int v = [] { const char* e = getenv("DC_GEMM_PERSIST_MAXK"); return e ? atoi(e) : 2560; }();
     return v;
 }
 
