@@ -265,7 +265,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_conv_kernel(const DcGemmParams 
                 const float4 rv = *reinterpret_cast<const float4*>(p.rowvec + (size_t)(m / p.rows_per_vec) * p.rowvec_ld + n);
                 v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
             }
-            v.x *= p.alpha; v.y *= p.alpha; v.z *= p.alpha; v.w *= p.alpha;
+            if (p.alpha != 1.0f) { v.x *= p.alpha; v.y *= p.alpha; v.z *= p.alpha; v.w *= p.alpha; }
             if (out_f32) {
                 *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.C) + (size_t)m * p.ldc + n) = v;
             } else {

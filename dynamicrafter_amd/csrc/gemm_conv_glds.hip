@@ -361,7 +361,7 @@ __global__ __launch_bounds__(GNT) void gemm_conv_glds_kernel(const DcGemmParams 
                 const float4 rv = *reinterpret_cast<const float4*>(p.rowvec + (size_t)(m / p.rows_per_vec) * p.rowvec_ld + n);
                 v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
             }
-            v.x *= p.alpha; v.y *= p.alpha; v.z *= p.alpha; v.w *= p.alpha;
+            if (p.alpha != 1.0f) { v.x *= p.alpha; v.y *= p.alpha; v.z *= p.alpha; v.w *= p.alpha; }
             if (out_f32) {
                 *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.C) + (size_t)m * p.ldc + n) = v;
             } else {
@@ -410,7 +410,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const DcGemmParams p
         const float4 rv = *reinterpret_cast<const float4*>(p.rowvec + (size_t)(m / p.rows_per_vec) * p.rowvec_ld + n);
         v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
     }
-    v.x *= p.alpha; v.y *= p.alpha; v.z *= p.alpha; v.w *= p.alpha;
+    if (p.alpha != 1.0f) { v.x *= p.alpha; v.y *= p.alpha; v.z *= p.alpha; v.w *= p.alpha; }
     if (p.flags & DC_GEMM_OUT_F32) {
         *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.C) + (size_t)m * p.ldc + n) = v;
         return;
@@ -663,7 +663,7 @@ __global__ __launch_bounds__(GNT) void gemm_persist_kernel(const DcGemmParams p)
                     const float4 r4 = *reinterpret_cast<const float4*>(rv + n);
                     v.x += r4.x; v.y += r4.y; v.z += r4.z; v.w += r4.w;
                 }
-                v.x *= p.alpha; v.y *= p.alpha; v.z *= p.alpha; v.w *= p.alpha;
+                if (p.alpha != 1.0f) { v.x *= p.alpha; v.y *= p.alpha; v.z *= p.alpha; v.w *= p.alpha; }
                 return v;
             };
             if constexpr (EPI == 2) {
