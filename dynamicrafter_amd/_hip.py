@@ -67,6 +67,8 @@ SIGNATURES = {
     "dc_add_rows": (_I, [_P, _I, _P, _I, _P, _I, _I, _I, _P]),
     "dc_vae_sample": (_I, [_P, _I, _P, _P, _I, _I, _I, _F, _P]),
     "dc_ddim_step": (_I, [C.POINTER(DcDdimParams), _P, _P, _P, _I, _P, _P, _P, _P, _I, _I, _I, _P, _P]),
+    "dc_frames_to_u8": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
+    "dc_mask_blend": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _L, _L, _I, _P]),
     "dc_advance_counter": (_I, [_P, _P]),
     "dc_stream_create": (_I, [C.POINTER(_P)]),
     "dc_stream_destroy": (_I, [_P]),

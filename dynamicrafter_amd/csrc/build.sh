@@ -9,7 +9,14 @@ FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -I$ROOT/include -I$HERE ${DC_E
 OBJDIR="${DC_OBJDIR:-$HERE}"
 OBJS=()
 pids=()
-for f in gemm_conv gemm_conv_glds norms attention elementwise runtime; do
+SRCS="gemm_conv gemm_conv_glds norms attention elementwise runtime"
+# objects of kernels that no longer exist must not ride along to the GPU box (or into a link by hand)
+for o in "$OBJDIR"/*.o; do
+  [ -e "$o" ] || continue
+  b="$(basename "$o" .o)"
+  case " $SRCS " in *" $b "*) ;; *) echo "removing stale object $o"; rm -f "$o" ;; esac
+done
+for f in $SRCS; do
   "$HIPCC" $FLAGS -c "$HERE/$f.hip" -o "$OBJDIR/$f.o" &
   pids+=($!)
   OBJS+=("$OBJDIR/$f.o")

@@ -275,8 +275,8 @@ __global__ __launch_bounds__(256) void ddim_partial_kernel(const DcDdimParams p,
 
 __global__ __launch_bounds__(256) void ddim_apply_kernel(const DcDdimParams p, const float* __restrict__ ec,
                                                          const float* __restrict__ eu, const float* __restrict__ ei,
-                                                         int ld_e, const float* __restrict__ x,
-                                                         const float* __restrict__ noise, float* __restrict__ x_prev,
+                                                         int ld_e, const float* x,      // x and x_prev may alias: the
+                                                         const float* __restrict__ noise, float* x_prev,   // sampler updates in place
                                                          float* __restrict__ pred_x0, int C, int THW,
                                                          const float* __restrict__ ws) {
     __shared__ double tot[4];
@@ -356,6 +356,47 @@ inline int grid_for(int64_t total, int block, int cap) {
     if (g > cap) g = cap;
     if (g < 1) g = 1;
     return (int)g;
+}
+
+
+// Inpainting-style blend ahead of a DDIM step (reference: lvdm/models/samplers/ddim.py:174-180): the latent is replaced by
+// the (re-noised: DDPM.q_sample ddpm3d.py:305-308) original wherever mask == 1. fp32, in place, one element per thread.
+__global__ void mask_blend_kernel(float* __restrict__ img, const float* __restrict__ x0, const float* __restrict__ mask,
+                                  const float* __restrict__ qnoise, const float* __restrict__ sqrt_acp,
+                                  const float* __restrict__ sqrt_1macp, const int32_t* __restrict__ step_index, int index,
+                                  int64_t n, int64_t noise_step_stride, int clean) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int idx = step_index ? step_index[0] : index;
+    float orig = x0[i];
+    if (!clean) {
+        const float q = qnoise[(step_index ? (int64_t)idx * noise_step_stride : 0) + i];
+        orig = sqrt_acp[idx] * orig + sqrt_1macp[idx] * q;
+    }
+    const float m = mask[i];
+    img[i] = orig * m + (1.0f - m) * img[i];
+}
+
+
+// Decoded clips -> display frames (reference: scripts/evaluation/inference.py:127-137, utils/save_video.py:35-42):
+// clamp to [-1,1], (v+1)/2, *255, truncate to uint8; n clips side by side (make_grid(nrow=n, padding=0)); layout
+// [t][h][n*w][c]. One thread per output pixel; reads are coalesced along w, writes along (w, c).
+__global__ void frames_to_u8_kernel(const float* __restrict__ video, uint8_t* __restrict__ out, int N, int C, int T, int H,
+                                    int W) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t total = (int64_t)T * H * N * W;
+    if (idx >= total) return;
+    const int gx = (int)(idx % ((int64_t)N * W));
+    const int64_t r = idx / ((int64_t)N * W);
+    const int y = (int)(r % H), t = (int)(r / H);
+    const int n = gx / W, x = gx - n * W;
+    for (int c = 0; c < C; ++c) {
+        float v = video[((((size_t)n * C + c) * T + t) * H + y) * W + x];
+        v = fminf(fmaxf(v, -1.0f), 1.0f);
+        v = (v + 1.0f) / 2.0f;
+        v = v * 255.0f;
+        out[(size_t)idx * C + c] = (uint8_t)v;                   // truncation, as Tensor.to(torch.uint8)
+    }
 }
 
 }  // namespace
@@ -479,6 +520,28 @@ extern "C" int dc_ddim_step(const DcDdimParams* pp, const float* e_cond, const f
     const int64_t n = (int64_t)C * THW;
     hipLaunchKernelGGL(ddim_apply_kernel, dim3(grid_for(n, 256, 1024), B), dim3(256), 0, stream, p, e_cond, e_uncond,
                        e_img, ld_e, x, noise, x_prev, pred_x0, C, THW, workspace);
+    DC_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int dc_frames_to_u8(const float* video, uint8_t* out, int N, int C, int T, int H, int W, void* stream_) {
+    if (!video || !out) return DC_ERR_ARG;
+    if (N < 1 || C < 1 || T < 1 || H < 1 || W < 1) return DC_ERR_SHAPE;
+    const int64_t total = (int64_t)T * H * N * W;
+    hipLaunchKernelGGL(frames_to_u8_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream_, video, out,
+                       N, C, T, H, W);
+    DC_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int dc_mask_blend(float* img, const float* x0, const float* mask, const float* qnoise, const float* sqrt_acp_t,
+                             const float* sqrt_1macp_t, const int32_t* step_index, int index, int64_t n,
+                             int64_t noise_step_stride, int clean, void* stream_) {
+    if (!img || !x0 || !mask) return DC_ERR_ARG;
+    if (!clean && (!qnoise || !sqrt_acp_t || !sqrt_1macp_t)) return DC_ERR_ARG;
+    if (n < 1) return DC_ERR_SHAPE;
+    hipLaunchKernelGGL(mask_blend_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream_, img, x0, mask,
+                       qnoise, sqrt_acp_t, sqrt_1macp_t, step_index, index, n, noise_step_stride, clean);
     DC_CHECK_LAUNCH();
     return 0;
 }

@@ -12,6 +12,8 @@ behaves as the reference's, including the 3-branch guidance of ddim_multiplecond
   * `noises=` (tensor [S, *x.shape]) injects the per-step Gaussian noise (parity tests); otherwise it is drawn
     with torch.randn on the device as the reference does (common.py:31-34).
   * sqrt(1 - a_prev - sigma^2) is clamped at 0 (the reference can produce NaN there: SURVEY §8 a2).
+  * `mask` / `x0` blending (reference :174-180) is one more kernel ahead of the step (dc_mask_blend: q_sample + blend),
+    inside the captured graph; `q_noises=` (tensor [S, *x.shape]) injects the q_sample draws (parity tests).
 """
 import numpy as np
 import torch
@@ -26,7 +28,7 @@ class FusedRun:
     index by one; after `S` steps `rewind()` starts the next clip."""
 
     def __init__(self, sampler, img, branches, *, fs=None, noises=None, cfg_scale=1.0, cfg_img=None,
-                 guidance_rescale=0.0, temperature=1.0):
+                 guidance_rescale=0.0, temperature=1.0, mask=None, x0=None, q_noises=None, clean_cond=False):
         m = sampler.model
         self.sampler, self.model = sampler, m
         self.img = img
@@ -45,9 +47,23 @@ class FusedRun:
                        cfg_scale=cfg_scale, cfg_img=cfg_scale if cfg_img is None else cfg_img,
                        guidance_rescale=guidance_rescale, temperature=temperature, noise_step_stride=img.numel())
         self.graph = None
+        # mask / x0 blending ahead of every step (ddim.py:174-180): the original latent, re-noised to the step's
+        # timestep with pre-drawn q_sample noise [S, ...] unless clean_cond
+        self.blend = None
+        if mask is not None:
+            assert x0 is not None
+            full = lambda t: t.to(device=dev, dtype=torch.float32).expand_as(img).contiguous()
+            if not clean_cond and q_noises is None:
+                q_noises = torch.randn((self.S,) + tuple(img.shape), device=dev)
+            self.blend = dict(x0=full(x0), mask=full(mask), clean=bool(clean_cond),
+                              q=None if clean_cond else q_noises.to(device=dev, dtype=torch.float32).contiguous())
 
     def _enqueue(self):
-        """Kernel launches of one step (no allocation, no host sync): batched UNet + fused DDIM update."""
+        """Kernel launches of one step (no allocation, no host sync): [mask blend +] batched UNet + fused DDIM update."""
+        if self.blend is not None:
+            b = self.blend
+            ops.mask_blend(self.img, b["x0"], b["mask"], b["q"], self.sampler._tables, step_index=self.counter,
+                           clean=b["clean"], noise_step_stride=self.img.numel())
         e = self.model.apply_model_rows(self.img, self.prep, self.t_table, t_index=self.counter)
         M = self.kw["B"] * self.kw["THW"]
         e_u = e[M:2 * M] if self.nb > 1 else None
@@ -197,9 +213,11 @@ class DDIMSampler(object):
         fast = hasattr(m, "apply_model_rows") and all(isinstance(c, dict) for c in branches)
         intermediates = {"x_inter": [img.clone()], "pred_x0": [img.clone()]}
 
-        if fast and mask is None:
+        q_noises = kwargs.pop("q_noises", None)
+        if fast:
             run = FusedRun(self, img, branches, fs=fs, noises=noises, cfg_scale=unconditional_guidance_scale,
-                           cfg_img=cfg_img, guidance_rescale=guidance_rescale, temperature=temperature)
+                           cfg_img=cfg_img, guidance_rescale=guidance_rescale, temperature=temperature, mask=mask,
+                           x0=x0, q_noises=q_noises, clean_cond=clean_cond)
             if use_graph:
                 run.capture()
             for i in range(S):
@@ -221,8 +239,12 @@ class DDIMSampler(object):
             ts = torch.full((b,), int(step), device=dev, dtype=torch.long)
             if mask is not None:
                 assert x0 is not None
-                img_orig = x0 if clean_cond else m.q_sample(x0, ts)
-                img = img_orig * mask + (1. - mask) * img
+                full = lambda t: t.to(device=dev, dtype=torch.float32).expand_as(img).contiguous()
+                qn = None
+                if not clean_cond:
+                    qn = torch.randn_like(img) if q_noises is None else q_noises[i].to(dev, torch.float32).contiguous()
+                img = ops.mask_blend(img.contiguous().clone(), full(x0), full(mask), qn, self._tables, index=i,
+                                     clean=clean_cond)
             img, pred_x0 = self.p_sample_ddim(img, cond, ts, index=index, temperature=temperature,
                                               unconditional_guidance_scale=unconditional_guidance_scale,
                                               unconditional_conditioning=unconditional_conditioning, fs=fs,

@@ -181,7 +181,7 @@ def gemm(a, pw, out, *, M=None, residual=None, rowvec=None, rows_per_vec=1, gegl
     p.flags = (_hip.DC_GEMM_OUT_F32 if out_f32 else 0) | (_hip.DC_GEMM_GEGLU if geglu else 0) | \
         (_hip.DC_GEMM_GELU if gelu else 0)
     p.alpha = alpha
-    ws = _gemm_workspace(a.device)
+    ws = _gemm_workspace(a.device, torch.cuda.current_stream().cuda_stream)
     p.workspace, p.workspace_bytes = ws.data_ptr(), ws.numel()
     if conv is not None:
         p.mode = 1
@@ -231,12 +231,14 @@ def gemm(a, pw, out, *, M=None, residual=None, rowvec=None, rows_per_vec=1, gegl
 _gemm_ws = {}
 
 
-def _gemm_workspace(device):
-    """One scratch buffer per device for split-K partial sums (launches on one stream use it one after another)."""
-    buf = _gemm_ws.get(device.index)
+def _gemm_workspace(device, stream):
+    """One scratch buffer per (device, stream) for split-K partial sums: launches on one stream use it one after
+    another; a graph replay on its private stream and eager work on another stream never share partials."""
+    key = (device.index, stream)
+    buf = _gemm_ws.get(key)
     if buf is None:
         buf = torch.empty(int(_hip.lib().dc_gemm_workspace_bytes()), dtype=torch.uint8, device=device)
-        _gemm_ws[device.index] = buf
+        _gemm_ws[key] = buf
     return buf
 
 
@@ -293,11 +295,18 @@ class Arena:
 _gn_ws = {}
 
 
+_gn_ws_retired = []
+
+
 def _gn_workspace(device, nbytes):
-    key = (device.index,)
+    """GroupNorm statistics scratch per (device, stream). A buffer that was ever handed out is never released: a captured
+    hipGraph keeps its address, so a larger request allocates a new buffer and the old one is parked, not freed."""
+    key = (device.index, torch.cuda.current_stream().cuda_stream)
     buf = _gn_ws.get(key)
     if buf is None or buf.numel() * 4 < nbytes:
-        buf = torch.empty((max(nbytes, 1 << 20) + 3) // 4, dtype=torch.float32, device=device)
+        if buf is not None:
+            _gn_ws_retired.append(buf)
+        buf = torch.empty((max(nbytes, 4 << 20) + 3) // 4, dtype=torch.float32, device=device)
         _gn_ws[key] = buf
     return buf
 
@@ -463,6 +472,23 @@ def ddim_step(tables, e_cond, e_uncond, e_img, x, noise, x_prev, pred_x0, worksp
     return x_prev, pred_x0
 
 
+def mask_blend(img, x0, mask, qnoise, tables, *, index=0, step_index=None, clean=False, noise_step_stride=0):
+    """img = orig*mask + (1-mask)*img in place, orig = x0 or its q_sample at the step's timestep (fp32, same shapes)."""
+    n = img.numel()
+    for t, nm in ((x0, "x0"), (mask, "mask")):
+        if t.dtype != torch.float32 or not t.is_contiguous() or t.numel() != n:
+            raise ValueError(f"mask_blend: {nm} must be contiguous fp32 of the latent's shape")
+    if img.dtype != torch.float32 or not img.is_contiguous():
+        raise ValueError("mask_blend: latent must be contiguous fp32")
+    if not clean:
+        need = n if step_index is None else n            # at least one step's worth; the sampler sizes it [S, ...]
+        _need(qnoise, need, "qnoise")
+    check(_hip.lib().dc_mask_blend(_ptr(img), _ptr(x0), _ptr(mask), _ptr(None if clean else qnoise),
+                                   _ptr(tables.get("sqrt_acp_t")), _ptr(tables.get("sqrt_1macp_t")), _ptr(step_index), index,
+                                   n, noise_step_stride, 1 if clean else 0, stream_ptr()), "dc_mask_blend")
+    return img
+
+
 def advance_counter(counter):
     check(_hip.lib().dc_advance_counter(_ptr(counter), stream_ptr()), "dc_advance_counter")
 
@@ -481,6 +507,17 @@ class DeviceGraph:
     def capture(self, fn):
         l = _hip.lib()
         torch.cuda.synchronize()
+        # the per-stream workspaces of the capture stream must exist before capture begins (no allocation inside a
+        # capture): size them like the ones the eager warm-up used on the current stream
+        cur = torch.cuda.current_stream()
+        dev = cur.device
+        cap = self.torch_stream.cuda_stream
+        if (dev.index, cur.cuda_stream) in _gemm_ws:
+            _gemm_workspace(dev, cap)
+        like = _gn_ws.get((dev.index, cur.cuda_stream))
+        if like is not None:
+            with torch.cuda.stream(self.torch_stream):
+                _gn_workspace(dev, like.numel() * 4)
         with torch.cuda.stream(self.torch_stream):
             check(l.dc_graph_begin_capture(self._stream), "dc_graph_begin_capture")
             try:

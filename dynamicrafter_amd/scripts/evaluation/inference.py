@@ -20,7 +20,15 @@ from ...lvdm.models.samplers.ddim_multiplecond import DDIMSampler as DDIMSampler
 
 def load_model_checkpoint(model, ckpt):
     """inference.py:34-59. `ckpt` is a path (torch.load) or an already loaded mapping."""
-    state_dict = torch.load(ckpt, map_location="cpu") if isinstance(ckpt, (str, bytes)) or hasattr(ckpt, "__fspath__") else ckpt
+    if isinstance(ckpt, (str, bytes)) or hasattr(ckpt, "__fspath__"):
+        if str(ckpt).endswith(".safetensors"):
+            # flat tensor file with the same keys (the pruned community releases, reference README.md:384-385)
+            from safetensors.torch import load_file
+            state_dict = {"state_dict": load_file(str(ckpt), device="cpu")}
+        else:
+            state_dict = torch.load(ckpt, map_location="cpu")
+    else:
+        state_dict = ckpt
     if "state_dict" in state_dict:
         state_dict = state_dict["state_dict"]
         try:

@@ -174,6 +174,20 @@ int dc_ddim_step(const DcDdimParams* p, const float* e_cond, const float* e_unco
                  const float* x, const float* noise, float* x_prev, float* pred_x0, int B, int C, int THW,
                  float* workspace, void* stream);
 
+/* Decoded clips video[N][C][T][H][W] fp32 in [-1,1] -> display frames out[T][H][N*W][C] uint8: clamp, (v+1)/2, *255,
+ * truncation; the N clips of a batch side by side (torchvision make_grid(nrow=N, padding=0)).
+ * replaces scripts/evaluation/inference.py:127-137 (save_results) / :151-160 (save_results_seperate, N = 1),
+ * utils/save_video.py:35-42 */
+int dc_frames_to_u8(const float* video, uint8_t* out, int N, int C, int T, int H, int W, void* stream);
+
+/* Mask / x0 blend ahead of a DDIM step, in place on img [n] fp32: img = orig*mask + (1-mask)*img with
+ * orig = x0 (clean != 0) or sqrt_acp_t[i]*x0 + sqrt_1macp_t[i]*qnoise (q_sample of x0 at the step's timestep);
+ * i = step_index[0] (device counter; qnoise then starts at qnoise + i*noise_step_stride) or `index`.
+ * replaces lvdm/models/samplers/ddim.py:174-180 + DDPM.q_sample lvdm/models/ddpm3d.py:305-308 */
+int dc_mask_blend(float* img, const float* x0, const float* mask, const float* qnoise, const float* sqrt_acp_t,
+                  const float* sqrt_1macp_t, const int32_t* step_index, int index, int64_t n,
+                  int64_t noise_step_stride, int clean, void* stream);
+
 /* step_index[0] += 1 (device-side loop counter for the graph-captured sampler). */
 int dc_advance_counter(int32_t* counter, void* stream);
 

@@ -141,16 +141,22 @@ def p_sample_ddim(sched: DDIMSchedule, x, index, e_cond, e_uncond=None, e_img=No
 
 @torch.no_grad()
 def ddim_sample(apply_model, sched: DDIMSchedule, x_T, cond, uncond=None, *, cfg_scale=1.0, guidance_rescale=0.0,
-                noises=None, temperature=1.0, uncond_img=None, cfg_img=None, **model_kwargs):
+                noises=None, temperature=1.0, uncond_img=None, cfg_img=None, mask=None, x0=None, clean_cond=False,
+                q_noises=None, t_start=None, **model_kwargs):
     """DDIMSampler.ddim_sampling ddim.py:134-203 with injected x_T / per-step noise.
-    apply_model(x, t_long[b], cond_dict, **model_kwargs) -> model output."""
+    apply_model(x, t_long[b], cond_dict, **model_kwargs) -> model output.
+    mask / x0 (:174-180): before every step the latent is blended with the (re-noised, unless clean_cond) original;
+    q_noises[i] is the q_sample draw of step i. t_start: run only the last t_start DDIM steps (decode, :281-301)."""
     img = x_T
     b = img.shape[0]
-    ts = sched.ddim_timesteps
+    ts = sched.ddim_timesteps if t_start is None else sched.ddim_timesteps[:t_start]
     total = ts.shape[0]
     for i, step in enumerate(np.flip(ts)):
         index = total - i - 1
         tl = torch.full((b,), int(step), dtype=torch.long)
+        if mask is not None:
+            img_orig = x0 if clean_cond else q_sample(sched.ms, x0, tl, q_noises[i])
+            img = img_orig * mask + (1. - mask) * img
         e_c = apply_model(img, tl, cond, **model_kwargs)
         e_u = e_i = None
         if uncond is not None and cfg_scale != 1.0:
@@ -162,3 +168,20 @@ def ddim_sample(apply_model, sched: DDIMSchedule, x_T, cond, uncond=None, *, cfg
                                cfg_img=cfg_scale if cfg_img is None else cfg_img, guidance_rescale=guidance_rescale,
                                noise=nz, temperature=temperature)
     return img
+
+
+def q_sample(ms: ModelSchedule, x_start, t, noise):
+    """DDPM.q_sample ddpm3d.py:305-308"""
+    shp = (t.shape[0],) + (1,) * (x_start.dim() - 1)
+    return ms.sqrt_alphas_cumprod[t].reshape(shp) * x_start + ms.sqrt_one_minus_alphas_cumprod[t].reshape(shp) * noise
+
+
+def stochastic_encode(sched: DDIMSchedule, x0, t, noise, use_original_steps=False):
+    """DDIMSampler.stochastic_encode ddim.py:303-317: t indexes the DDIM tables (or the 1000-step ones)."""
+    shp = (t.shape[0],) + (1,) * (x0.dim() - 1)
+    if use_original_steps:
+        sa, s1 = sched.ms.sqrt_alphas_cumprod, sched.ms.sqrt_one_minus_alphas_cumprod
+    else:
+        sa = torch.sqrt(sched.raw["ddim_alphas"])
+        s1 = torch.as_tensor(sched.raw["ddim_sqrt_one_minus_alphas"])
+    return sa[t].reshape(shp) * x0 + s1[t].reshape(shp) * noise

@@ -72,16 +72,37 @@ def _mlp(sd, p, x):
     return _lin(sd, p + ".2", F.silu(_lin(sd, p + ".0", x)))
 
 
-def attention_core(q, k, v, heads, scale):
+# score-matrix budget (bytes) above which attention_core walks (batch*head, query) chunks instead of materialising
+# softmax(q k^T) whole: the reference's plain path needs 80 x 9216 x 9216 fp32 = 27 GB at the 1024 config
+# (SURVEY 8a12); per-row softmax makes the chunked result identical up to BLAS blocking (pinned in
+# tests/test_oracle_golden.py::test_chunked_attention_matches_plain).
+ATTN_CHUNK_BYTES = 1 << 30
+
+
+def attention_core(q, k, v, heads, scale, chunk_bytes=None):
     """attention.py:101-125: per-head softmax(q k^T * scale) v on [b, n, h*d] tensors."""
     b, n, _ = q.shape
     d = q.shape[-1] // heads
     qh = q.reshape(b, n, heads, d).transpose(1, 2)
     kh = k.reshape(b, -1, heads, d).transpose(1, 2)
     vh = v.reshape(b, -1, heads, d).transpose(1, 2)
-    sim = torch.matmul(qh, kh.transpose(-1, -2)) * scale
-    p = sim.softmax(dim=-1)
-    return torch.matmul(p, vh).transpose(1, 2).reshape(b, n, heads * d)
+    L = kh.shape[2]
+    budget = ATTN_CHUNK_BYTES if chunk_bytes is None else chunk_bytes
+    if 4 * b * heads * n * L <= budget:
+        sim = torch.matmul(qh, kh.transpose(-1, -2)) * scale
+        p = sim.softmax(dim=-1)
+        return torch.matmul(p, vh).transpose(1, 2).reshape(b, n, heads * d)
+    # chunked: rows of the score matrix are independent, so any (batch*head, query-range) partition is exact
+    qf, kf, vf = qh.reshape(b * heads, n, d), kh.reshape(b * heads, L, d), vh.reshape(b * heads, L, d)
+    out = torch.empty_like(qf)
+    qc = max(1, min(n, budget // (4 * L)))              # query rows per chunk for one (batch, head)
+    gc = max(1, budget // (4 * L * qc))                 # (batch, head) pairs per chunk
+    for g0 in range(0, b * heads, gc):
+        kt = kf[g0:g0 + gc].transpose(-1, -2)
+        for q0 in range(0, n, qc):
+            sim = torch.matmul(qf[g0:g0 + gc, q0:q0 + qc], kt) * scale
+            out[g0:g0 + gc, q0:q0 + qc] = torch.matmul(sim.softmax(dim=-1), vf[g0:g0 + gc])
+    return out.reshape(b, heads, n, d).transpose(1, 2).reshape(b, n, heads * d)
 
 
 def cross_attention(sd, p, x, context, heads, dim_head, cfg, image_cross):

@@ -30,6 +30,10 @@ class AECfg:
         return AECfg(embed_dim=embed_dim, **kw)
 
 
+# the 576x1024 frame has 9216 mid-block positions: the score matrix is walked in query chunks above this many bytes
+ATTN_CHUNK_BYTES = 1 << 28
+
+
 def _swish(x):
     return x * torch.sigmoid(x)          # ae_modules.py:10-12
 
@@ -58,10 +62,15 @@ def attn_block(sd, p, x):
     b, c, h, w = q.shape
     q = q.reshape(b, c, h * w).permute(0, 2, 1)
     k = k.reshape(b, c, h * w)
-    w_ = torch.bmm(q, k) * (int(c) ** (-0.5))
-    w_ = F.softmax(w_, dim=2)
     v = v.reshape(b, c, h * w)
-    h_ = torch.bmm(v, w_.permute(0, 2, 1)).reshape(b, c, h, w)
+    n = h * w
+    rows = max(1, min(n, ATTN_CHUNK_BYTES // (4 * n * b)))     # query rows per chunk (rows are independent: exact)
+    out = torch.empty(b, c, n, dtype=x.dtype)
+    for q0 in range(0, n, rows):
+        w_ = torch.bmm(q[:, q0:q0 + rows], k) * (int(c) ** (-0.5))
+        w_ = F.softmax(w_, dim=2)
+        out[:, :, q0:q0 + rows] = torch.bmm(v, w_.permute(0, 2, 1))
+    h_ = out.reshape(b, c, h, w)
     return x + _conv(sd, p + ".proj_out", h_)
 
 

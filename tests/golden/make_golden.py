@@ -400,9 +400,170 @@ def gen_resampler():
         save(f"resampler_{tag}", x=x, y=y, param_names=np.array(sorted(shapes)), yaml_params=np.array(yaml.safe_dump(kw)))
 
 
+
+def gen_unet_fullsize():
+    """The released 1.44 B-parameter UNet run by the REFERENCE at the real latent sizes of BASELINE.json configs 1 and
+    2/5: inference_256 (eps, learnable alpha, fs 3) at 16x32x32 and inference_512 at 16x40x64 with the interp (config 5)
+    conditioning pattern - the concat half of the input is zero except frames 0 and 15 (inference.py:246-249), fs 5.
+    (72x128 cannot run through the reference's plain attention on 64 GB: 80 x 9216^2 fp32 scores; that size is
+    covered by the chunked oracle, which these two fixtures pin at full width and real token counts.)"""
+    from lvdm.modules.networks.openaimodel3d import UNetModel
+    for tag, cname, (h, w), fsv, interp in (("256_32x32", "inference_256_v1.0.yaml", (32, 32), 3, False),
+                                            ("512_40x64_interp", "inference_512_v1.0.yaml", (40, 64), 5, True)):
+        cfg = yaml.safe_load(open(os.path.join(REF, "configs", cname)))
+        params = cfg["model"]["params"]["unet_config"]["params"]
+        params["use_checkpoint"] = False
+        net = UNetModel(**params).eval()
+        load_recipe_weights(net, seed=12)
+        b, t = 1, 16
+        xn = rnd(b, 4, t, h, w, seed=131)
+        cc = rnd(b, 4, t, h, w, seed=132) * 0.18215 * 4
+        if interp:
+            cc[:, :, 1:-1] = 0.0
+        else:
+            cc = cc[:, :, :1].repeat(1, 1, t, 1, 1)
+        ctx = rnd(b, 77 + t * 16, 1024, seed=133)
+        ts = torch.tensor([759], dtype=torch.long)
+        fs = torch.tensor([fsv], dtype=torch.long)
+        import time
+        t0 = time.time()
+        with torch.no_grad():
+            y = net(torch.cat([xn, cc], 1), ts, context=ctx, fs=fs)
+        print(f"  reference forward {tag}: {time.time() - t0:.1f} s")
+        # inputs are stored in fp16-exact form? no: store seeds' tensors as they are (fp32) - a few MB
+        save(f"unet_fullsize_{tag}", x=xn, c_concat=cc, context=ctx, timesteps=ts.numpy(), fs=fs.numpy(), y=y,
+             yaml_params=np.array(yaml.safe_dump(params)))
+        del net
+
+
+def gen_trajectory50():
+    """The bench runs 50 eta=1 steps; the 10-step fixtures cannot show drift over that length. Same tiny network and
+    settings as trajectory_512 (v-param + ZTSNR + dynamic rescale + guidance rescale 0.7, uniform_trailing), S=50."""
+    import lvdm.models.samplers.ddim as ddim_mod
+    Sampler = cpu_sampler_cls(ddim_mod.DDIMSampler)
+    model, p = build_lvd("inference_512_v1.0.yaml", dict(TINY_UNET), TINY_AE)
+    load_recipe_weights(model.model.diffusion_model, seed=11)
+    b, t, h, w = 1, 4, 16, 16
+    S = 50
+    x_T = rnd(b, 4, t, h, w, seed=161)
+    cond = {"c_crossattn": [rnd(b, 77 + 16 * t, 128, seed=162)], "c_concat": [rnd(b, 4, t, h, w, seed=163) * 0.18215]}
+    uc = {"c_crossattn": [rnd(b, 77 + 16 * t, 128, seed=164)], "c_concat": cond["c_concat"]}
+    noises = [rnd(b, 4, t, h, w, seed=1700 + i) for i in range(S)]
+    it = iter(noises)
+    ddim_mod.noise_like = lambda shp, dev, rep=False: next(it)
+    s = Sampler(model)
+    fs = torch.tensor([p["unet_config"]["params"]["default_fs"]] * b, dtype=torch.long)
+    samples, inter = s.sample(S=S, batch_size=b, shape=(4, t, h, w), conditioning=cond, verbose=False,
+                              unconditional_guidance_scale=7.5, unconditional_conditioning=uc, eta=1.0,
+                              x_T=x_T, fs=fs, timestep_spacing="uniform_trailing", guidance_rescale=0.7, log_every_t=10)
+    save("trajectory50_512", x_T=x_T, ctx=cond["c_crossattn"][0], uc_ctx=uc["c_crossattn"][0],
+         c_concat=cond["c_concat"][0], noises=torch.stack(noises), fs=fs.numpy(), samples=samples,
+         x_inter=torch.stack(inter["x_inter"]), noise_seeds=np.array([1700 + i for i in range(S)]))
+
+
+def gen_sampler_extras():
+    """SURVEY 8(f) rank 2 remainder, from the reference sampler on the tiny 512-config model: (1) mask / x0 blending
+    inside ddim_sampling (ddim.py:174-180; q_sample noise injected through torch.randn_like), also with clean_cond;
+    (2) decode() from an intermediate latent (:281-301); (3) stochastic_encode() (:303-317)."""
+    import lvdm.models.samplers.ddim as ddim_mod
+    Sampler = cpu_sampler_cls(ddim_mod.DDIMSampler)
+    model, p = build_lvd("inference_512_v1.0.yaml", dict(TINY_UNET), TINY_AE)
+    load_recipe_weights(model.model.diffusion_model, seed=11)
+    b, t, h, w = 1, 4, 16, 16
+    S = 6
+    x_T = rnd(b, 4, t, h, w, seed=181)
+    x0 = rnd(b, 4, t, h, w, seed=182)
+    mask = (rnd(b, 1, t, h, w, seed=183) > 0).float().expand(b, 4, t, h, w).contiguous()
+    cond = {"c_crossattn": [rnd(b, 77 + 16 * t, 128, seed=184)], "c_concat": [rnd(b, 4, t, h, w, seed=185) * 0.18215]}
+    uc = {"c_crossattn": [rnd(b, 77 + 16 * t, 128, seed=186)], "c_concat": cond["c_concat"]}
+    noises = [rnd(b, 4, t, h, w, seed=190 + i) for i in range(S)]
+    qnoises = [rnd(b, 4, t, h, w, seed=200 + i) for i in range(S)]
+    fs = torch.tensor([24] * b, dtype=torch.long)
+    out = dict(x_T=x_T, x0=x0, mask=mask, ctx=cond["c_crossattn"][0], uc_ctx=uc["c_crossattn"][0],
+               c_concat=cond["c_concat"][0], noises=torch.stack(noises), qnoises=torch.stack(qnoises), fs=fs.numpy())
+    orig_rl = torch.randn_like
+    for tag, clean in (("mask", False), ("mask_clean", True)):
+        it_n, it_q = iter(noises), iter(qnoises)
+        ddim_mod.noise_like = lambda shp, dev, rep=False: next(it_n)
+        torch.randn_like = lambda x, **k: next(it_q)
+        try:
+            s = Sampler(model)
+            samples, _ = s.sample(S=S, batch_size=b, shape=(4, t, h, w), conditioning=cond, verbose=False, mask=mask,
+                                  x0=x0, unconditional_guidance_scale=7.5, unconditional_conditioning=uc, eta=1.0,
+                                  x_T=x_T, fs=fs, timestep_spacing="uniform_trailing", guidance_rescale=0.7,
+                                  clean_cond=clean)
+        finally:
+            torch.randn_like = orig_rl
+        out[f"{tag}/samples"] = samples
+    # decode(): last t_start DDIM steps from a latent, eta=0 schedule, default fs (decode passes no fs)
+    s = Sampler(model)
+    s.make_schedule(S, ddim_discretize="uniform", ddim_eta=0.0, verbose=False)
+    ddim_mod.noise_like = lambda shp, dev, rep=False: torch.zeros(shp)
+    x_lat = rnd(b, 4, t, h, w, seed=187)
+    out["decode/x_latent"] = x_lat
+    out["decode/t_start"] = np.array(4)
+    out["decode/x_dec"] = s.decode(x_lat, cond, 4, unconditional_guidance_scale=7.5, unconditional_conditioning=uc)
+    # stochastic_encode(): both table choices
+    tt = torch.tensor([3], dtype=torch.long)
+    n_enc = rnd(b, 4, t, h, w, seed=188)
+    out["enc/t"] = tt.numpy(); out["enc/noise"] = n_enc
+    out["enc/ddim"] = s.stochastic_encode(x0, tt, use_original_steps=False, noise=n_enc)
+    tt2 = torch.tensor([640], dtype=torch.long)
+    out["enc/t_orig"] = tt2.numpy()
+    out["enc/orig"] = s.stochastic_encode(x0, tt2, use_original_steps=True, noise=n_enc)
+    save("sampler_extras", **out)
+
+
+def gen_harness_interp512():
+    """BASELINE.json config 5 ('512_interp'): the 512 YAML (v-param, ZTSNR, dynamic rescale) driven as
+    scripts/run_application.sh:8-28 does - interp=True (first + last frame concat), fs=5, uniform_trailing,
+    guidance_rescale 0.7, eta=1 - through the reference's image_guided_synthesis; tiny nets, 5 steps."""
+    import importlib.util
+    from tests.golden_cfg import TINY_RESAMPLER
+    spec = importlib.util.spec_from_file_location("ref_inference", os.path.join(REF, "scripts", "evaluation", "inference.py"))
+    inf = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(inf)
+    import lvdm.models.samplers.ddim as ddim_mod
+    import lvdm.models.samplers.ddim_multiplecond as mc_mod
+    inf.DDIMSampler = cpu_sampler_cls(ddim_mod.DDIMSampler)
+    inf.DDIMSampler_multicond = cpu_sampler_cls(mc_mod.DDIMSampler)
+    kw = dict(ddim_steps=5, ddim_eta=1.0, unconditional_guidance_scale=7.5, fs=5, text_input=True, interp=True,
+              timestep_spacing="uniform_trailing", guidance_rescale=0.7)
+    model, p = build_lvd("inference_512_v1.0.yaml", dict(TINY_UNET), TINY_AE,
+                         conditioners=dict(cond_stage_config={"target": "tests.golden_cfg.ToyTextEmbedder"},
+                                           img_cond_stage_config={"target": "tests.golden_cfg.ToyImageEmbedder"},
+                                           image_proj_stage_config={"target": "lvdm.modules.encoders.resampler.Resampler",
+                                                                    "params": dict(TINY_RESAMPLER)}))
+    load_recipe_weights(model.model.diffusion_model, seed=11)
+    load_recipe_weights(model.first_stage_model, seed=13)
+    load_recipe_weights(model.image_proj_model, seed=14)
+    b, t, H, W = 1, 4, 64, 128
+    h, w = H // 8, W // 8
+    videos = rnd(b, 3, t, H, W, seed=141).clamp(-1, 1)
+    videos[:, :, 1:-1] = 0.0                                   # load_data_prompts(interp): frames between are unused
+    x_T = rnd(b, 4, t, h, w, seed=142)
+    S = kw["ddim_steps"]
+    noises = [rnd(b, 4, t, h, w, seed=150 + i) for i in range(S)]
+    ae_noise = [rnd(1, 4, h, w, seed=160 + i) for i in range(b * t)]
+    it_n, it_a = iter(noises), iter(ae_noise)
+    ddim_mod.noise_like = lambda shp, dev, rep=False: next(it_n)
+    orig = torch.randn
+    torch.randn = lambda *a, **k: next(it_a)
+    try:
+        with torch.no_grad():
+            out = inf.image_guided_synthesis(model, ["two frames of a blooming flower"], videos, [b, 4, t, h, w],
+                                             n_samples=1, x_T=x_T, **kw)
+    finally:
+        torch.randn = orig
+    assert out.shape == (b, 1, 3, t, H, W), out.shape
+    save("harness_c", videos=videos, x_T=x_T, noises=torch.stack(noises), ae_noise=torch.cat(ae_noise, 0), out=out,
+         kwargs=np.array(yaml.safe_dump(kw)))
+
+
 GENS = dict(resampler=gen_resampler, unet_tiny=gen_unet_tiny, unet_fullwidth=gen_unet_fullwidth, ae=gen_ae, schedules=gen_schedules,
             p_sample=gen_p_sample_known_answers, trajectory=gen_trajectory, first_stage=gen_first_stage,
-            harness=gen_harness)
+            harness=gen_harness, unet_fullsize=gen_unet_fullsize, trajectory50=gen_trajectory50,
+            sampler_extras=gen_sampler_extras, harness_interp512=gen_harness_interp512)
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()

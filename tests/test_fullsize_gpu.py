@@ -1,0 +1,239 @@
+"""Parity AT THE SIZES BASELINE.json NAMES: the released 1.44 B-parameter UNet (recipe weights) at the real latents of
+configs 1 / 2+5 / 3 (16x32x32, 16x40x64, 16x72x128), evaluated exactly as the sampler issues it (cond + uncond as one
+batch-2 forward through `prepare_branches` / `apply_model_rows`, shared guidance prefix on), plus one fused DDIM
+update, and one 576x1024 AutoencoderKL frame - against
+
+  (a) the CPU oracle (oracle/unet.py with the chunked softmax pinned in tests/test_oracle_golden.py) on the box's host
+      cores, both guidance branches, and
+  (b) outputs of the REFERENCE itself run at 16x32x32 (256 config) and 16x40x64 (512 config, interp conditioning =
+      BASELINE config 5) - tests/golden/unet_fullsize_*.npz; the same fixtures pin the oracle at full size.
+
+These are the kernel dispatch shapes of the benchmarked step: persistent / split-K GEMM plans at M = 294 912, flash
+attention L = 9 216, GroupNorm over 147 456 (5-D) and 589 824 (AE) rows per instance.
+
+Stated tolerances (bf16 storage and MFMA inputs, fp32 accumulate; oracle/reference fp32) - set at <= 2x the values
+measured on MI355X, which every test prints:
+  UNet forward, each branch    rel-L2 <= 1.2e-2, cosine >= 0.9999
+  fused DDIM update (x_prev)   rel-L2 <= 1e-1 of the oracle's update from the oracle's own model outputs (CFG 7.5
+                               amplifies the branch difference's error)
+  AE encode moments / decode   rel-L2 <= 8e-3 / 1.2e-2
+  oracle vs reference fixture  max-rel <= 1e-4 (fp32 both, different summation orders over K up to 23 040)
+"""
+import gc
+import os
+import time
+
+import numpy as np
+import pytest
+import torch
+import yaml
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+HERE = os.path.dirname(os.path.abspath(__file__))
+G = os.path.join(HERE, "golden")
+CFG_DIR = os.path.join(HERE, "..", "dynamicrafter_amd", "configs")
+
+UNET_TOL, UNET_COS = 1.2e-2, 0.9999
+STEP_TOL = 1e-1
+AE_ENC_TOL, AE_DEC_TOL = 8e-3, 1.2e-2
+
+
+def rel_l2(a, b):
+    a = torch.as_tensor(a).float().cpu(); b = torch.as_tensor(b).float().cpu()
+    return ((a - b).norm() / b.norm().clamp_min(1e-12)).item()
+
+
+def cosine(a, b):
+    a = torch.as_tensor(a).double().cpu().flatten(); b = torch.as_tensor(b).double().cpu().flatten()
+    return (a @ b / (a.norm() * b.norm())).item()
+
+
+def maxrel(a, b):
+    a = torch.as_tensor(a).double().cpu(); b = torch.as_tensor(b).double().cpu()
+    return ((a - b).abs().max() / b.abs().max().clamp_min(1e-30)).item()
+
+
+def _threads():
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    return max(1, min(n, 16))
+
+
+def _build(cname):
+    """This package's LatentVisualDiffusion from the released YAML (Identity conditioners, as bench.py) with the
+    per-name seeded recipe weights in the UNet; returns (model on the GPU, oracle cfg, oracle state dict)."""
+    from dynamicrafter_amd.utils.utils import instantiate_from_config
+    from oracle import unet as ounet
+    from oracle.weights import fill_state_dict
+    cfg = yaml.safe_load(open(os.path.join(CFG_DIR, cname)))
+    p = cfg["model"]["params"]
+    for k in ("cond_stage_config", "img_cond_stage_config", "image_proj_stage_config"):
+        p[k] = {"target": "torch.nn.Identity"}
+    model = instantiate_from_config(cfg["model"])
+    ocfg = ounet.UNetCfg.from_params(p["unet_config"]["params"])
+    sd = fill_state_dict(ounet.unet_param_shapes(ocfg), seed=12)
+    model.model.diffusion_model.load_state_dict(sd, strict=True)
+    return model.to(DEV).eval(), ocfg, sd
+
+
+def _rnd(*shape, seed):
+    return torch.randn(*shape, generator=torch.Generator().manual_seed(seed))
+
+
+def _run_case(model, ocfg, sd, *, x, cc, ctx, uc_ctx, fs, disc, eta, gr, tag, golden_y=None, golden_t=None):
+    """One guided evaluation at full size: batched HIP forward of both branches + one fused DDIM step vs the oracle."""
+    from dynamicrafter_amd.lvdm.models.samplers.ddim import DDIMSampler, FusedRun
+    from oracle import ddim as oddim
+    from oracle import unet as ounet
+    torch.set_num_threads(_threads())
+    B, _, T, H, W = x.shape
+    S = 50
+    sampler = DDIMSampler(model)
+    sampler.make_schedule(S, ddim_discretize=disc, ddim_eta=eta, verbose=False)
+    cond = {"c_crossattn": [ctx.to(DEV)], "c_concat": [cc.to(DEV)]}
+    uc = {"c_crossattn": [uc_ctx.to(DEV)], "c_concat": [cc.to(DEV)]}
+    noises = _rnd(S, *x.shape, seed=77)
+    img = x.to(DEV).clone()
+    run = FusedRun(sampler, img, [cond, uc], fs=fs.to(DEV), noises=noises.to(DEV), cfg_scale=7.5, guidance_rescale=gr)
+    assert run.prep["share"] == 2                        # the shared-prefix path the bench runs
+    if golden_t is not None:                               # evaluate at the fixture's timestep instead of step 0's
+        run.t_table[0] = int(golden_t)
+    t_step = int(run.t_table[0, 0].item())
+    e = model.apply_model_rows(img, run.prep, run.t_table, t_index=run.counter)
+    torch.cuda.synchronize()
+    M = B * T * H * W
+    e = e.detach().float().cpu().reshape(2, B, T, H, W, 4).permute(0, 1, 5, 2, 3, 4).contiguous()   # [branch,B,4,T,H,W]
+    # ---- oracle: both branches as one batch-2 forward
+    t0 = time.perf_counter()
+    xin = torch.cat([x, cc], 1)
+    ref = ounet.unet_forward(sd, ocfg, torch.cat([xin, xin], 0), torch.full((2 * B,), t_step, dtype=torch.long),
+                             torch.cat([ctx, uc_ctx], 0), torch.cat([fs, fs], 0))
+    dt = time.perf_counter() - t0
+    ref = ref.reshape(2, B, 4, T, H, W)
+    r = [rel_l2(e[k], ref[k]) for k in range(2)]
+    c = [cosine(e[k], ref[k]) for k in range(2)]
+    print(f"\n[fullsize {tag}] latent {T}x{H}x{W} t={t_step}: HIP vs oracle rel-L2 cond {r[0]:.3e} uncond {r[1]:.3e}, "
+          f"cosine {c[0]:.6f} {c[1]:.6f}; oracle batch-2 forward {dt:.1f} s on {_threads()} threads")
+    if golden_y is not None:
+        mo, rg = maxrel(ref[0], golden_y), rel_l2(e[0], golden_y)
+        print(f"[fullsize {tag}] oracle vs REFERENCE fixture max-rel {mo:.2e}; HIP vs REFERENCE rel-L2 {rg:.3e}")
+        assert mo < 1e-4
+        assert rg < UNET_TOL
+    assert torch.isfinite(e).all()
+    assert max(r) < UNET_TOL and min(c) > UNET_COS
+    # ---- one fused DDIM update on the same state (eager launches; the graph replays exactly these)
+    x_prev = None
+    if golden_t is None:
+        run.step()
+        run.sync()
+        torch.cuda.synchronize()
+        x_prev = run.img.detach().float().cpu()
+    return dict(e=e, ref=ref, x_prev=x_prev, noises=noises, t_step=t_step, S=S)
+
+
+def _oracle_step(tag, ref, x, noise, S, disc, eta, gr, index):
+    from oracle import ddim as oddim
+    if tag == "256":
+        ms = oddim.ModelSchedule(parameterization="eps")
+    else:
+        ms = oddim.ModelSchedule(rescale_betas_zero_snr=True, parameterization="v", use_dynamic_rescale=True,
+                                 base_scale=0.7 if tag == "512" else 0.3)
+    sc = oddim.DDIMSchedule(ms, S, disc, eta)
+    xp, _ = oddim.p_sample_ddim(sc, x, index, ref[0], ref[1], None, cfg_scale=7.5, guidance_rescale=gr, noise=noise)
+    return xp
+
+
+@pytest.fixture(scope="module")
+def model_v():
+    """The 512 / 1024 configs share one architecture (they differ in latent size, base_scale, default fs)."""
+    m = _build("inference_1024_v1.0.yaml")
+    yield m
+    del m
+    gc.collect()
+    torch.cuda.empty_cache()
+
+
+def test_unet_72x128_config3(model_v):
+    """BASELINE config 3 (the benchmarked workload): inference_1024, latent 16x72x128, first executed step (t = 999,
+    zero terminal SNR), CFG batch 2, guidance rescale 0.7, eta = 1."""
+    model, ocfg, sd = model_v
+    B, T, H, W = 1, 16, 72, 128
+    x = _rnd(B, 4, T, H, W, seed=301)
+    cc = (_rnd(B, 4, 1, H, W, seed=302) * 0.18215 * 4).repeat(1, 1, T, 1, 1).contiguous()
+    ctx, uc_ctx = _rnd(B, 77 + 16 * T, 1024, seed=303), _rnd(B, 77 + 16 * T, 1024, seed=304)
+    fs = torch.tensor([10])
+    out = _run_case(model, ocfg, sd, x=x, cc=cc, ctx=ctx, uc_ctx=uc_ctx, fs=fs, disc="uniform_trailing", eta=1.0, gr=0.7,
+                    tag="1024")
+    xp = _oracle_step("1024", out["ref"], x, out["noises"][0], out["S"], "uniform_trailing", 1.0, 0.7, out["S"] - 1)
+    r = rel_l2(out["x_prev"], xp)
+    print(f"[fullsize 1024] fused DDIM step x_prev vs oracle rel-L2 {r:.3e}")
+    assert r < STEP_TOL
+
+
+def test_unet_40x64_config2_and_5(model_v):
+    """BASELINE configs 2 and 5: the 512 model at latent 16x40x64 with the interp conditioning pattern (concat latent
+    zero except frames 0 and 15, fs = 5); cond branch also against the reference's own output."""
+    model, ocfg, sd = model_v
+    g = np.load(os.path.join(G, "unet_fullsize_512_40x64_interp.npz"))
+    x, cc, ctx = (torch.from_numpy(g[k]) for k in ("x", "c_concat", "context"))
+    assert float(cc[:, :, 1:-1].abs().max()) == 0.0 and float(cc[:, :, 0].abs().max()) > 0
+    uc_ctx = _rnd(*ctx.shape, seed=314)
+    fs = torch.from_numpy(g["fs"])
+    # the 512 YAML differs from the 1024 one only in scalars that enter through the sampler tables / the fs input
+    # (base_scale, default_fs): the UNet evaluation is the same network
+    out = _run_case(model, ocfg, sd, x=x, cc=cc, ctx=ctx, uc_ctx=uc_ctx, fs=fs, disc="uniform_trailing", eta=1.0,
+                    gr=0.7, tag="512-interp", golden_y=torch.from_numpy(g["y"])[0], golden_t=int(g["timesteps"][0]))
+    assert out["t_step"] == int(g["timesteps"][0])
+
+
+def test_unet_32x32_config1():
+    """BASELINE config 1: inference_256 (eps-parameterisation, learnable image-attention scale, fs 3) at 16x32x32,
+    `uniform` spacing, eta = 0, no guidance rescale; cond branch also against the reference's own output."""
+    model, ocfg, sd = _build("inference_256_v1.0.yaml")
+    try:
+        g = np.load(os.path.join(G, "unet_fullsize_256_32x32.npz"))
+        x, cc, ctx = (torch.from_numpy(g[k]) for k in ("x", "c_concat", "context"))
+        uc_ctx = _rnd(*ctx.shape, seed=324)
+        fs = torch.from_numpy(g["fs"])
+        out = _run_case(model, ocfg, sd, x=x, cc=cc, ctx=ctx, uc_ctx=uc_ctx, fs=fs, disc="uniform", eta=0.0, gr=0.0,
+                        tag="256", golden_y=torch.from_numpy(g["y"])[0], golden_t=int(g["timesteps"][0]))
+        assert out["t_step"] == int(g["timesteps"][0])
+    finally:
+        del model, sd
+        gc.collect()
+        torch.cuda.empty_cache()
+
+
+def test_autoencoder_576x1024_frame():
+    """One production frame (576x1024 -> 72x128 latent) through the released AutoencoderKL configuration: encoder
+    moments, posterior sample, decoder - vs oracle/vae.py (mid-block attention over 9216 positions, chunked)."""
+    from dynamicrafter_amd.lvdm.models.autoencoder import AutoencoderKL
+    from oracle import vae as ovae
+    from oracle.weights import fill_state_dict
+    torch.set_num_threads(_threads())
+    cfg = yaml.safe_load(open(os.path.join(CFG_DIR, "inference_1024_v1.0.yaml")))
+    fp = cfg["model"]["params"]["first_stage_config"]["params"]
+    ae = AutoencoderKL(ddconfig=fp["ddconfig"], lossconfig=fp["lossconfig"], embed_dim=fp["embed_dim"])
+    acfg = ovae.AECfg.from_params(fp["ddconfig"], embed_dim=fp["embed_dim"])
+    sd = fill_state_dict(ovae.ae_param_shapes(acfg), seed=13)
+    ae.load_state_dict(sd, strict=True)
+    ae.to(DEV)
+    img = torch.rand(1, 3, 576, 1024, generator=torch.Generator().manual_seed(331)) * 2 - 1
+    noise = _rnd(1, 4, 72, 128, seed=332)
+    post = ae.encode(img.to(DEV))
+    z = post.sample(noise=noise.to(DEV))
+    rec = ae.decode(z)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    mom_ref = ovae.encode_moments(sd, acfg, img)
+    z_ref = ovae.posterior_sample(mom_ref, noise)
+    rec_ref = ovae.decode(sd, acfg, z.float().cpu())           # decoder parity on the HIP latent (same input both sides)
+    dt = time.perf_counter() - t0
+    r_m, r_z, r_d = rel_l2(post.parameters, mom_ref), rel_l2(z, z_ref), rel_l2(rec, rec_ref)
+    print(f"\n[fullsize AE] 576x1024 frame: moments rel-L2 {r_m:.3e}, z {r_z:.3e}, decode {r_d:.3e}; "
+          f"oracle encode+decode {dt:.1f} s")
+    assert tuple(rec.shape) == (1, 3, 576, 1024) and torch.isfinite(rec).all()
+    assert r_m < AE_ENC_TOL and r_z < AE_ENC_TOL and r_d < AE_DEC_TOL

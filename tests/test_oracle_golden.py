@@ -192,11 +192,12 @@ def test_resampler_matches_reference(tag):
     assert maxrel(y, g["y"]) < 2e-5
 
 
-@pytest.mark.parametrize("tag,cname", [("a", "512"), ("b", "256")])
+@pytest.mark.parametrize("tag,cname", [("a", "512"), ("b", "256"), ("c", "512")])
 def test_harness_matches_reference(tag, cname):
     """oracle/harness.py against scripts/evaluation/inference.py:image_guided_synthesis of the reference (toy CLIP
     stand-ins -> Resampler -> conditioning assembly -> DDIM loop -> AE decode): 2-branch eta=1 with guidance rescale
-    (512 config) and interp + 3-branch guidance (256 config)."""
+    (512 config), interp + 3-branch guidance (256 config), and BASELINE config 5: the 512 YAML in interp mode (fs 5,
+    uniform_trailing, guidance rescale, eta 1; scripts/run_application.sh:8-28)."""
     from oracle import harness as oh
     from oracle import resampler  # noqa: F401
     from tests.golden_cfg import TINY_AE, TINY_RESAMPLER, TINY_UNET, ToyImageEmbedder, ToyTextEmbedder
@@ -228,7 +229,73 @@ def test_harness_matches_reference(tag, cname):
     out = oh.image_guided_synthesis(
         unet_sd=usd, unet_cfg=ucfg, ae_sd=asd, ae_cfg=acfg, proj_sd=psd, proj_heads=r["heads"], proj_depth=r["depth"],
         embed_image=ToyImageEmbedder(), embed_text=ToyTextEmbedder().encode, schedule=_ms_for(cname), scale_factor=0.18215,
-        uncond_type="empty_seq", prompts=["a corgi running on the beach"], videos=videos, x_T=T(g["x_T"]),
-        noises=T(g["noises"]), ae_noise=noise, **kw)
+        uncond_type="empty_seq", prompts=["two frames of a blooming flower" if tag == "c" else "a corgi running on the beach"], videos=videos,
+        x_T=T(g["x_T"]), noises=T(g["noises"]), ae_noise=noise, **kw)
     assert tuple(out.shape) == tuple(g["out"].shape)
     assert maxrel(out, g["out"]) < 5e-4
+
+
+def test_chunked_attention_matches_plain(monkeypatch):
+    """The full-size parity tests (72x128 latent: 9216 tokens) run the oracle's attention in (batch*head, query) chunks;
+    rows of softmax(q k^T) are independent, so the chunked walk must reproduce the plain path the goldens pin."""
+    g = torch.Generator().manual_seed(4)
+    q, k, v = (torch.randn(3, 50, 128, generator=g) for _ in range(3))
+    plain = ounet.attention_core(q, k, v, 2, 0.125, chunk_bytes=1 << 40)
+    for budget in (4 * 50 * 7, 4 * 50 * 50 * 2, 4 * 50):           # part of a head / two heads / a single query row
+        ch = ounet.attention_core(q, k, v, 2, 0.125, chunk_bytes=budget)
+        assert maxrel(ch, plain) < 2e-6
+    # whole UNet (tiny golden) with every attention chunked
+    g2 = load("unet_tiny_v1024")
+    params = yaml.safe_load(str(g2["yaml_params"]))
+    cfg = ounet.UNetCfg.from_params(params)
+    sd = fill_state_dict(ounet.unet_param_shapes(cfg), seed=11)
+    monkeypatch.setattr(ounet, "ATTN_CHUNK_BYTES", 4096)
+    y = ounet.unet_forward(sd, cfg, T(g2["x"]), T(g2["timesteps"]), T(g2["context"]), T(g2["fs"]))
+    assert maxrel(y, g2["y"]) < 2e-5
+    # AE mid-block attention in query chunks
+    ga = load("ae_tiny")
+    acfg = ovae.AECfg.from_params(yaml.safe_load(str(ga["yaml_params"])), embed_dim=4)
+    asd = fill_state_dict(ovae.ae_param_shapes(acfg), seed=13)
+    monkeypatch.setattr(ovae, "ATTN_CHUNK_BYTES", 4 * 96 * 2 * 5)
+    assert maxrel(ovae.encode_moments(asd, acfg, T(ga["img"])), ga["moments"]) < 2e-5
+    assert maxrel(ovae.decode(asd, acfg, T(ga["z"])), ga["rec"]) < 5e-5
+
+
+def _tiny512():
+    from tests.golden_cfg import TINY_UNET
+    cfg = ounet.UNetCfg.from_params(dict(TINY_UNET, default_fs=24))
+    return cfg, fill_state_dict(ounet.unet_param_shapes(cfg), seed=11)
+
+
+def test_trajectory50_matches_reference():
+    """50 eta=1 steps (the length the bench runs) of the reference sampler on the tiny 512-config model."""
+    g = load("trajectory50_512")
+    cfg, sd = _tiny512()
+    sc = oddim.DDIMSchedule(_ms_for("512"), 50, "uniform_trailing", 1.0)
+    cc = T(g["c_concat"])
+    out = oddim.ddim_sample(lambda x, t, c, fs=None: ounet.unet_forward(sd, cfg, torch.cat([x, cc], 1), t, c, fs), sc,
+                            T(g["x_T"]), T(g["ctx"]), T(g["uc_ctx"]), cfg_scale=7.5, guidance_rescale=0.7,
+                            noises=list(T(g["noises"])), fs=T(g["fs"]))
+    assert maxrel(out, g["samples"]) < 1e-3
+
+
+def test_sampler_extras_match_reference():
+    """mask / x0 blending (ddim.py:174-180, with and without clean_cond), decode (:281-301), stochastic_encode (:303-317)."""
+    g = load("sampler_extras")
+    cfg, sd = _tiny512()
+    ms = _ms_for("512")
+    cc = T(g["c_concat"])
+    am = lambda x, t, c, fs=None: ounet.unet_forward(sd, cfg, torch.cat([x, cc], 1), t, c, fs)
+    sc = oddim.DDIMSchedule(ms, 6, "uniform_trailing", 1.0)
+    for tag, clean in (("mask", False), ("mask_clean", True)):
+        out = oddim.ddim_sample(am, sc, T(g["x_T"]), T(g["ctx"]), T(g["uc_ctx"]), cfg_scale=7.5, guidance_rescale=0.7,
+                                noises=list(T(g["noises"])), fs=T(g["fs"]), mask=T(g["mask"]), x0=T(g["x0"]),
+                                clean_cond=clean, q_noises=list(T(g["qnoises"])))
+        assert maxrel(out, g[f"{tag}/samples"]) < 2e-4, tag
+    sc0 = oddim.DDIMSchedule(ms, 6, "uniform", 0.0)
+    dec = oddim.ddim_sample(am, sc0, T(g["decode/x_latent"]), T(g["ctx"]), T(g["uc_ctx"]), cfg_scale=7.5,
+                            t_start=int(g["decode/t_start"]))              # decode() passes no fs: default_fs
+    assert maxrel(dec, g["decode/x_dec"]) < 2e-4
+    x0, n = T(g["x0"]), T(g["enc/noise"])
+    assert maxrel(oddim.stochastic_encode(sc0, x0, T(g["enc/t"]), n), g["enc/ddim"]) < 1e-6
+    assert maxrel(oddim.stochastic_encode(sc0, x0, T(g["enc/t_orig"]), n, use_original_steps=True), g["enc/orig"]) < 1e-6
