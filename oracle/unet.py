@@ -72,14 +72,18 @@ def _mlp(sd, p, x):
     return _lin(sd, p + ".2", F.silu(_lin(sd, p + ".0", x)))
 
 
-# score-matrix budget (bytes) above which attention_core walks (batch*head, query) chunks instead of materialising
-# softmax(q k^T) whole: the reference's plain path needs 80 x 9216 x 9216 fp32 = 27 GB at the 1024 config
-# (SURVEY 8a12); per-row softmax makes the chunked result identical up to BLAS blocking (pinned in
-# tests/test_oracle_golden.py::test_chunked_attention_matches_plain).
+# Score-matrix budget (bytes) above which attention_core does not materialise softmax(q k^T) whole: the reference's
+# plain path (attention.py:101-125) needs 80 x 9216 x 9216 fp32 = 27 GB per level-0 attention at the 1024 config
+# (SURVEY 8a12), which is why the reference itself switches to a fused online-softmax kernel there
+# (xformers.memory_efficient_attention, attention.py:146-209). Above the budget the oracle does the same with torch's
+# CPU counterpart, F.scaled_dot_product_attention ("sdpa"), or walks (batch*head, query) chunks of the plain path
+# ("chunked": rows of the score matrix are independent). Both are pinned to the plain path in
+# tests/test_oracle_golden.py::test_large_attention_paths_match_plain.
 ATTN_CHUNK_BYTES = 1 << 30
+ATTN_LARGE_IMPL = "sdpa"
 
 
-def attention_core(q, k, v, heads, scale, chunk_bytes=None):
+def attention_core(q, k, v, heads, scale, chunk_bytes=None, impl=None):
     """attention.py:101-125: per-head softmax(q k^T * scale) v on [b, n, h*d] tensors."""
     b, n, _ = q.shape
     d = q.shape[-1] // heads
@@ -92,6 +96,9 @@ def attention_core(q, k, v, heads, scale, chunk_bytes=None):
         sim = torch.matmul(qh, kh.transpose(-1, -2)) * scale
         p = sim.softmax(dim=-1)
         return torch.matmul(p, vh).transpose(1, 2).reshape(b, n, heads * d)
+    if (ATTN_LARGE_IMPL if impl is None else impl) == "sdpa":
+        o = F.scaled_dot_product_attention(qh, kh, vh, scale=scale)
+        return o.transpose(1, 2).reshape(b, n, heads * d)
     # chunked: rows of the score matrix are independent, so any (batch*head, query-range) partition is exact
     qf, kf, vf = qh.reshape(b * heads, n, d), kh.reshape(b * heads, L, d), vh.reshape(b * heads, L, d)
     out = torch.empty_like(qf)

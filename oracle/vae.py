@@ -32,6 +32,7 @@ class AECfg:
 
 # the 576x1024 frame has 9216 mid-block positions: the score matrix is walked in query chunks above this many bytes
 ATTN_CHUNK_BYTES = 1 << 28
+ATTN_LARGE_IMPL = "sdpa"
 
 
 def _swish(x):
@@ -64,12 +65,18 @@ def attn_block(sd, p, x):
     k = k.reshape(b, c, h * w)
     v = v.reshape(b, c, h * w)
     n = h * w
-    rows = max(1, min(n, ATTN_CHUNK_BYTES // (4 * n * b)))     # query rows per chunk (rows are independent: exact)
-    out = torch.empty(b, c, n, dtype=x.dtype)
-    for q0 in range(0, n, rows):
-        w_ = torch.bmm(q[:, q0:q0 + rows], k) * (int(c) ** (-0.5))
-        w_ = F.softmax(w_, dim=2)
-        out[:, :, q0:q0 + rows] = torch.bmm(v, w_.permute(0, 2, 1))
+    if 4 * n * n * b > ATTN_CHUNK_BYTES and ATTN_LARGE_IMPL == "sdpa":
+        # fused online-softmax path for the 9216-position production frame (see oracle/unet.py:ATTN_LARGE_IMPL)
+        o = F.scaled_dot_product_attention(q[:, None], k.permute(0, 2, 1)[:, None], v.permute(0, 2, 1)[:, None],
+                                           scale=int(c) ** (-0.5))
+        out = o[:, 0].permute(0, 2, 1)
+    else:
+        rows = max(1, min(n, ATTN_CHUNK_BYTES // (4 * n * b)))     # query rows per chunk (rows are independent: exact)
+        out = torch.empty(b, c, n, dtype=x.dtype)
+        for q0 in range(0, n, rows):
+            w_ = torch.bmm(q[:, q0:q0 + rows], k) * (int(c) ** (-0.5))
+            w_ = F.softmax(w_, dim=2)
+            out[:, :, q0:q0 + rows] = torch.bmm(v, w_.permute(0, 2, 1))
     h_ = out.reshape(b, c, h, w)
     return x + _conv(sd, p + ".proj_out", h_)
 
