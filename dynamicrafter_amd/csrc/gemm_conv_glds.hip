@@ -740,11 +740,23 @@ __global__ __launch_bounds__(GNT) void gemm_persist_kernel(const DcGemmParams p)
     }
 }
 
+template <int BN, bool GEGLU, int EPI, int MODE, int ST_FORCE>
+int launch_persist_epi_st(const DcGemmParams& p, hipStream_t stream, int grid);
+
 template <int BN, bool GEGLU, int EPI, int MODE>
 int launch_persist_epi(const DcGemmParams& p, hipStream_t stream, int grid) {
+    // tool switch (tools/gemm_probe.py): DC_GEMM_STAGES=2 runs the <= 128-wide tiles on a 2-deep ring to expose what the
+    // prefetch depth is worth on HBM-sourced operands
+    static const int st = [] { const char* e = getenv("DC_GEMM_STAGES"); return e ? atoi(e) : 0; }();
+    if constexpr (BN <= 128 && MODE == 0 && !GEGLU) { if (st == 2) return launch_persist_epi_st<BN, GEGLU, EPI, MODE, 2>(p, stream, grid); }
+    return launch_persist_epi_st<BN, GEGLU, EPI, MODE, 0>(p, stream, grid);
+}
+
+template <int BN, bool GEGLU, int EPI, int MODE, int ST_FORCE>
+int launch_persist_epi_st(const DcGemmParams& p, hipStream_t stream, int grid) {
     // ring depth by LDS budget (160 KB minus 8 x 2 KB of epilogue patches): 64-wide 3 x 40 KB, 128-wide 3 x 48 KB,
     // 256/320-wide 2 x 64/72 KB
-    constexpr int ST = (BN <= 128) ? 3 : 2;
+    constexpr int ST = ST_FORCE ? ST_FORCE : ((BN <= 128) ? 3 : 2);
     constexpr size_t lds = (size_t)ST * (GBM * GBK * 2 + BN * GBK * 2) + 8 * 2048;
     static_assert(lds <= 163840, "LDS budget");
     static bool configured = false;

@@ -295,7 +295,11 @@ class LatentDiffusion(DDPM):
         same_cc = all((c is ccs[0]) or (c is not None and ccs[0] is not None and c.shape == ccs[0].shape
                                          and bool(torch.equal(c, ccs[0]))) for c in ccs)
         share = nb if (same_cc and nb > 1 and os.environ.get("DC_SHARED_PREFIX", "1") != "0") else 1
-        return dict(nb=nb, ccs=ccs, ctx_all=ctx_all, Lc=Lc, fs_table=fs_table, shape=tuple(x_shape), share=share)
+        # the cross-attention K/V projections of the context are step-invariant too (attention.py:128-136): computed here,
+        # once per sampler call, instead of in every UNet forward of every step
+        ctx_kv = net.precompute_context_kv(ctx_all) if os.environ.get("DC_HOIST_CTX_KV", "1") != "0" else None
+        return dict(nb=nb, ccs=ccs, ctx_all=ctx_all, Lc=Lc, fs_table=fs_table, shape=tuple(x_shape), share=share,
+                    ctx_kv=ctx_kv)
 
     def apply_model_rows(self, x, prep, t_table, t_index=None):
         """All branches of `prep` on the same latent x as ONE batched UNet forward (kernel launches only; safe
@@ -311,7 +315,8 @@ class LatentDiffusion(DDPM):
             ops.pack_latent(x, cc, xr[k * M:(k + 1) * M], B=B, Cx=Cx, Cc=0 if cc is None else cc.shape[1], T=T, HW=H * W)
         Lc = prep["Lc"]
         return net.forward_rows(xr, t_table, prep["ctx_all"], B=nb * B, T=T, H=H, W=W, Lc=Lc, n_text=min(77, Lc),
-                                fs_table=prep["fs_table"], t_index=t_index, shared_prefix=prep.get("share", 1))
+                                fs_table=prep["fs_table"], t_index=t_index, shared_prefix=prep.get("share", 1),
+                                ctx_kv=prep.get("ctx_kv"))
 
 
 class LatentVisualDiffusion(LatentDiffusion):

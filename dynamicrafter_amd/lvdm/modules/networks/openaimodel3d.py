@@ -222,10 +222,27 @@ class UNetModel(nn.Module):
                          image_cross_attention_scale_learnable=image_cross_attention_scale_learnable,
                          fs_condition=fs_condition, use_linear=use_linear)
         self._layout = _block_layout(self._cfg)
+        # skip-connection plan: up block u consumes cat([h, skip]) where skip is the output of down block n-1-u. Both
+        # producers write straight into their column range of one buffer per up block (no torch.cat copy,
+        # reference openaimodel3d.py:596): _cat_plan[u] = (channels of h, channels of the skip)
+        self._cat_plan = self._make_cat_plan()
         attach_params(self, _shape_table(self._cfg))
         self._packed = None
         self._arena = _Arena()
         self.register_load_state_dict_post_hook(lambda m, k: setattr(m, "_packed", None))
+
+    def _make_cat_plan(self):
+        down_path, middle, up_path = self._layout
+        out_ch = lambda blk: [a.get("cout", a.get("ch")) for k, a in blk if k in ("conv_in", "res", "down", "up")][-1]
+        widths = [out_ch(b) for b in down_path]
+        ch = out_ch(middle)
+        plan = []
+        for blk in up_path:
+            skip = widths.pop()
+            assert blk[0][1]["cin"] == ch + skip
+            plan.append((ch, skip))
+            ch = out_ch(blk)
+        return plan
 
     # ------------------------------------------------------------------ weights -> device layout
     def _p(self, name):
@@ -339,7 +356,7 @@ class UNetModel(nn.Module):
         y = self._arena.get(tag, x.shape[0], x.shape[1], device=x.device)
         return ops.layernorm(x, y, wb[0], wb[1], 1e-5)
 
-    def _res(self, W, x, g, out_tag):
+    def _res(self, W, x, g, out_tag, out=None):
         A = self._arena
         M, dev = x.shape[0], x.device
         cout = W["conv1"].N
@@ -354,7 +371,8 @@ class UNetModel(nn.Module):
         if "skip" in W:
             skip = ops.gemm(x, W["skip"], A.get("res_skip", M, cout, device=dev))
         has_tc = "tc" in W
-        h2 = ops.gemm(h, W["conv2"], A.get("res_h2" if has_tc else out_tag, M, cout, device=dev), conv=conv,
+        final = (lambda: out if out is not None else A.get(out_tag, M, cout, device=dev))
+        h2 = ops.gemm(h, W["conv2"], A.get("res_h2", M, cout, device=dev) if has_tc else final(), conv=conv,
                       residual=skip)
         if not has_tc:
             return h2
@@ -363,7 +381,7 @@ class UNetModel(nn.Module):
         for i, (gnw, cw) in enumerate(W["tc"]):
             n = self._gn(r, gnw, "gn", n_inst=g["B"], rpi=g["T"] * g["HW"], eps=1e-5, silu=True)
             last = i == 3
-            dst = A.get(out_tag if last else ("res_ta" if i % 2 == 0 else "res_tb"), M, cout, device=dev)
+            dst = final() if last else A.get("res_ta" if i % 2 == 0 else "res_tb", M, cout, device=dev)
             r = ops.gemm(n, cw, dst, tconv=tc, residual=h2 if last else None)
         return r
 
@@ -400,15 +418,34 @@ class UNetModel(nn.Module):
         B_ = W["blk"]
         return self._attn_self_spatial(B_["attn1"], self._ln(h, B_["norm1"], "ln"), h, g, heads)
 
-    def _spatial_post(self, W, x, h, g, heads, out_tag):
+    def _context_kv(self, B_, ctx, tag):
+        """k/v (text) and k_ip/v_ip (image) projections of the per-frame context rows: one GEMM [F*Lc, 4C] (attention.py
+        :128-136). The context does not change across the DDIM steps: the sampler path computes these once per run
+        (precompute_context_kv), outside the captured step."""
+        return ops.gemm(ctx, B_["kv_ctx"], self._arena.get(tag, ctx.shape[0], B_["kv_ctx"].N, device=ctx.device))
+
+    def precompute_context_kv(self, ctx_rows):
+        """All cross-attention K/V projections of a run's (step-invariant) context rows -> {id(block weights): kv}."""
+        Wt = self.packed(ctx_rows.device)
+        down_path, middle, up_path = self._layout
+        out = {}
+        for name, blks, Ws in (("in", down_path, Wt["in"]), ("mid", [middle], [Wt["mid"]]), ("out", up_path, Wt["out"])):
+            for i, (blk, Wb) in enumerate(zip(blks, Ws)):
+                for j, ((kind, a), W) in enumerate(zip(blk, Wb)):
+                    if kind == "spatial":
+                        out[id(W["blk"])] = self._context_kv(W["blk"], ctx_rows, f"kvctx.{name}{i}.{j}")
+        return out
+
+    def _spatial_post(self, W, x, h, g, heads, out_tag, out=None):
         """dual cross-attention (shared q; text keys, then image keys accumulated with the image scale), FF, proj_out."""
         A = self._arena
         M, dev, Cc = x.shape[0], x.device, x.shape[1]
         B_ = W["blk"]
         n = self._ln(h, B_["norm2"], "ln")
         q = ops.gemm(n, B_["q2"], A.get("q2", M, Cc, device=dev))
-        ctx = g["ctx"]                                   # rows [F * Lc, D], Lc = n_text + L_img
-        kv = ops.gemm(ctx, B_["kv_ctx"], A.get("kvctx", ctx.shape[0], B_["kv_ctx"].N, device=dev))
+        kv = None if g.get("ctx_kv") is None else g["ctx_kv"].get(id(B_))
+        if kv is None:
+            kv = self._context_kv(B_, g["ctx"], "kvctx")       # rows [F * Lc, 4C], Lc = n_text + L_img
         att = A.get("att", M, Cc, device=dev)
         Lc, nt = g["Lc"], g["n_text"]
         ops.flash_attn(q, kv[:, :Cc], kv[:, Cc:2 * Cc], att, batch=g["F"], heads=heads, Lq=g["HW"], Lk=nt, scale=0.125,
@@ -418,12 +455,12 @@ class UNetModel(nn.Module):
                            Lk=Lc - nt, scale=0.125, kv_bstride=Lc, accumulate=True, acc_scale=B_["ip_scale"])
         h = ops.gemm(att, B_["out2"], h, residual=h)
         h = self._ff(B_, h)
-        return ops.gemm(h, W["proj_out"], A.get(out_tag, M, Cc, device=dev), residual=x)
+        return ops.gemm(h, W["proj_out"], out if out is not None else A.get(out_tag, M, Cc, device=dev), residual=x)
 
-    def _spatial(self, W, x, g, heads, out_tag):
-        return self._spatial_post(W, x, self._spatial_pre(W, x, g, heads), g, heads, out_tag)
+    def _spatial(self, W, x, g, heads, out_tag, out=None):
+        return self._spatial_post(W, x, self._spatial_pre(W, x, g, heads), g, heads, out_tag, out=out)
 
-    def _temporal(self, W, x, g, heads, out_tag):
+    def _temporal(self, W, x, g, heads, out_tag, out=None):
         A = self._arena
         M, dev, Cc = x.shape[0], x.device, x.shape[1]
         inner = W["proj_in"].N
@@ -433,46 +470,54 @@ class UNetModel(nn.Module):
         h = self._attn_self_temporal(B_["attn1"], self._ln(h, B_["norm1"], "ln"), h, g, heads)
         h = self._attn_self_temporal(B_["attn2"], self._ln(h, B_["norm2"], "ln"), h, g, heads)
         h = self._ff(B_, h)
-        return ops.gemm(h, W["proj_out"], A.get(out_tag, M, Cc, device=dev), residual=x)
+        return ops.gemm(h, W["proj_out"], out if out is not None else A.get(out_tag, M, Cc, device=dev), residual=x)
 
-    def _run_block(self, blk, Wb, h, g, tag):
+    def _run_block(self, blk, Wb, h, g, tag, final=None):
+        """`final(rows, cols)` -> the tensor the LAST layer of the block must write (a column range of a skip-concat
+        buffer); None = a scratch buffer of its own."""
         A = self._arena
         for j, ((kind, a), W) in enumerate(zip(blk, Wb)):
             out_tag = f"{tag}.{j}"
             dev = h.device
+            last = final is not None and j == len(blk) - 1
             if kind == "conv_in":
                 conv = dict(IH=g["H"], IW=g["W"], OH=g["H"], OW=g["W"], stride=1, pad=1, ups=0)
-                h = ops.gemm(h, W["conv"], A.get(out_tag, h.shape[0], a["cout"], device=dev), conv=conv)
+                dst = final(h.shape[0], a["cout"]) if last else A.get(out_tag, h.shape[0], a["cout"], device=dev)
+                h = ops.gemm(h, W["conv"], dst, conv=conv)
             elif kind == "res":
-                h = self._res(W, h, g, out_tag)
+                h = self._res(W, h, g, out_tag, out=final(h.shape[0], a["cout"]) if last else None)
             elif kind == "spatial":
-                h = self._spatial(W, h, g, a["heads"], out_tag)
+                h = self._spatial(W, h, g, a["heads"], out_tag, out=final(h.shape[0], a["ch"]) if last else None)
             elif kind == "temporal":
-                h = self._temporal(W, h, g, a["heads"], out_tag)
+                h = self._temporal(W, h, g, a["heads"], out_tag, out=final(h.shape[0], a["ch"]) if last else None)
             elif kind == "down":
                 OH, OW = (g["H"] + 1) // 2, (g["W"] + 1) // 2       # 3x3 s2 p1: floor((H-1)/2)+1
                 conv = dict(IH=g["H"], IW=g["W"], OH=OH, OW=OW, stride=2, pad=1, ups=0)
-                h = ops.gemm(h, W["conv"], A.get(out_tag, g["F"] * OH * OW, a["ch"], device=dev), conv=conv)
+                rows = g["F"] * OH * OW
+                h = ops.gemm(h, W["conv"], final(rows, a["ch"]) if last else A.get(out_tag, rows, a["ch"], device=dev), conv=conv)
                 g["H"], g["W"], g["HW"] = OH, OW, OH * OW
             elif kind == "up":
                 OH, OW = g["H"] * 2, g["W"] * 2
                 conv = dict(IH=g["H"], IW=g["W"], OH=OH, OW=OW, stride=1, pad=1, ups=1)
-                h = ops.gemm(h, W["conv"], A.get(out_tag, g["F"] * OH * OW, a["ch"], device=dev), conv=conv)
+                rows = g["F"] * OH * OW
+                h = ops.gemm(h, W["conv"], final(rows, a["ch"]) if last else A.get(out_tag, rows, a["ch"], device=dev), conv=conv)
                 g["H"], g["W"], g["HW"] = OH, OW, OH * OW
         return h
 
     # ------------------------------------------------------------------ forward on rows
-    def _replicate(self, src, tag, nrep):
+    def _replicate(self, src, tag, nrep, dst=None):
         """rows [M, C] -> [nrep*M, C] (the guidance branches start from identical activations)"""
-        dst = self._arena.get(tag, nrep * src.shape[0], src.shape[1], device=src.device)
+        if dst is None:
+            dst = self._arena.get(tag, nrep * src.shape[0], src.shape[1], device=src.device)
         for k in range(nrep):
             ops.copy2d(src, dst[k * src.shape[0]:(k + 1) * src.shape[0]])
         return dst
 
     def forward_rows(self, xrows, t_table, ctx_rows, *, B, T, H, W, Lc, n_text=77, fs_table=None, t_index=None,
-                     shared_prefix=1):
+                     shared_prefix=1, ctx_kv=None):
         """xrows: bf16 [B*T*H*W, 64] (latent+concat channels, zero padded); t_table int64 [*, B] (row selected by
-        the device counter t_index, or row 0); ctx_rows bf16 [B*T*Lc, context_dim]; fs_table int64 [B].
+        the device counter t_index, or row 0); ctx_rows bf16 [B*T*Lc, context_dim]; fs_table int64 [B];
+        ctx_kv: precompute_context_kv(ctx_rows) or None (projected here).
         Returns fp32 rows [B*T*H*W, 4] (channels-last model output)."""
         dev = xrows.device
         Wt = self.packed(dev)
@@ -490,10 +535,26 @@ class UNetModel(nn.Module):
             ops.timestep_embedding(fs_table, femb, mc)
             ops.gemv_small(femb, Wt["fps0"], hid, act_out=1)
             ops.gemv_small(hid, Wt["fps2"], emb, accumulate=True)
-        g = dict(B=B, T=T, F=B * T, H=H, W=W, HW=H * W, emb=emb, ctx=ctx_rows, Lc=Lc, n_text=n_text)
+        g = dict(B=B, T=T, F=B * T, H=H, W=W, HW=H * W, emb=emb, ctx=ctx_rows, Lc=Lc, n_text=n_text, ctx_kv=ctx_kv)
         down_path, middle, up_path = self._layout
+        n_up = len(up_path)
+
+        # Skip connections without a concat copy (reference: torch.cat([h, hs.pop()], dim=1), openaimodel3d.py:596):
+        # up block u reads ONE buffer cat{u} = [h | skip]; the down block that produces the skip and the block that
+        # produces h each write their column range of it directly (every kernel takes a row stride).
+        cat_rows = {}
+
+        def cat_view(u, rows, part):
+            ch, cs = self._cat_plan[u]
+            if cat_rows.setdefault(u, rows) != rows:
+                raise ValueError("skip / decoder resolution mismatch (the latent height and width must divide by 8)")
+            buf = A.get(f"cat{u}", rows, ch + cs, device=dev)
+            return buf[:, :ch] if part == "h" else buf[:, ch:]
+
+        def skip_dst(d):                       # output of down block d = the skip half of up block n-1-d's input
+            return lambda rows, cols: cat_view(n_up - 1 - d, rows, "skip")
+
         h = xrows
-        skips = []
         first = 0
         nrep = shared_prefix
         if nrep > 1 and len(down_path) > 1 and [k for k, _ in down_path[1]][:2] == ["res", "spatial"]:
@@ -505,34 +566,38 @@ class UNetModel(nn.Module):
             h = self._run_block(down_path[0], Wt["in"][0], h[:B1 * T * H * W], g1, "in0")
             if self.addition_attention:
                 h = self._temporal(Wt["init_attn"], h, g1, 8, "init_attn")
-            skips.append((self._replicate(h, "in0.rep", nrep), H, W))
+            self._replicate(h, None, nrep, dst=skip_dst(0)(nrep * h.shape[0], h.shape[1]))
             blk, Wb = down_path[1], Wt["in"][1]
             r = self._res(Wb[0], h, g1, "in1.0")
             hh = self._spatial_pre(Wb[1], r, g1, blk[1][1]["heads"])
             r_full = self._replicate(r, "in1.0.rep", nrep)
             h_full = self._replicate(hh, "tr_h.rep", nrep)
-            h = self._spatial_post(Wb[1], r_full, h_full, g, blk[1][1]["heads"], "in1.1")
+            last = len(blk) - 1
+            fin = skip_dst(1)
+            h = self._spatial_post(Wb[1], r_full, h_full, g, blk[1][1]["heads"], "in1.1",
+                                   out=fin(r_full.shape[0], r_full.shape[1]) if last == 1 else None)
             for j in range(2, len(blk)):
                 kind, a = blk[j]
                 assert kind == "temporal"
-                h = self._temporal(Wb[j], h, g, a["heads"], f"in1.{j}")
-            skips.append((h, H, W))
+                h = self._temporal(Wb[j], h, g, a["heads"], f"in1.{j}", out=fin(h.shape[0], a["ch"]) if j == last else None)
             first = 2
         for i, blk in enumerate(down_path):
             if i < first:
                 continue
-            h = self._run_block(blk, Wt["in"][i], h, g, f"in{i}")
             if i == 0 and self.addition_attention:
-                h = self._temporal(Wt["init_attn"], h, g, 8, "init_attn")
-            skips.append((h, g["H"], g["W"]))
-        h = self._run_block(middle, Wt["mid"], h, g, "mid")
+                h = self._run_block(blk, Wt["in"][i], h, g, f"in{i}")
+                h = self._temporal(Wt["init_attn"], h, g, 8, "init_attn", out=skip_dst(0)(h.shape[0], h.shape[1]))
+            else:
+                h = self._run_block(blk, Wt["in"][i], h, g, f"in{i}", final=skip_dst(i))
+        h = self._run_block(middle, Wt["mid"], h, g, "mid", final=lambda rows, cols: cat_view(0, rows, "h"))
         for i, blk in enumerate(up_path):
-            s, sh, sw = skips.pop()
-            assert (sh, sw) == (g["H"], g["W"]), "skip / decoder resolution mismatch (latent size must divide by 8)"
-            cat = A.get("cat", h.shape[0], h.shape[1] + s.shape[1], device=dev)
-            ops.copy2d(h, cat[:, :h.shape[1]])
-            ops.copy2d(s, cat[:, h.shape[1]:])
-            h = self._run_block(blk, Wt["out"][i], cat, g, f"out{i}")
+            ch, cs = self._cat_plan[i]
+            if cat_rows.get(i) != h.shape[0]:
+                raise ValueError("skip / decoder resolution mismatch (the latent height and width must divide by 8)")
+            cat = A.get(f"cat{i}", h.shape[0], ch + cs, device=dev)
+            assert h.data_ptr() == cat.data_ptr() and h.shape[1] == ch
+            nxt = (lambda rows, cols, u=i + 1: cat_view(u, rows, "h")) if i + 1 < n_up else None
+            h = self._run_block(blk, Wt["out"][i], cat, g, f"out{i}", final=nxt)
         n = self._gn(h, Wt["out_gn"], "gn", n_inst=g["F"], rpi=g["HW"], eps=1e-5, silu=True)
         y = A.get("unet_out", h.shape[0], Wt["out_conv"].N, torch.float32, dev)
         conv = dict(IH=g["H"], IW=g["W"], OH=g["H"], OW=g["W"], stride=1, pad=1, ups=0)
