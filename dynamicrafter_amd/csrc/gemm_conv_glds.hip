@@ -440,9 +440,20 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const DcGemmParams p
 // already older than the hand-counted window, so each counted wait can only over-wait, never under-wait.
 // MODE as in gemm_conv_glds_kernel: 0 plain rows, 1 conv3x3 (no upsampling), 2 temporal 3-tap conv. The short-K convs
 // (level-0/1 ResBlock and TemporalConvBlock convs: 15-90 K tiles) gain from the same cross-tile pipelining.
+// EPI: 0 bf16 | 1 bf16 + residual loaded in the epilogue | 2 fp32 | 3 bf16 + residual streamed through the ring.
+// EPI 3: the residual tile [256 x BN] follows the K tiles of its output tile through the LDS ring as BN/64 more
+// A-operand tiles and is added on the MFMA pipe (acc += R * I with an identity weight fragment built in registers):
+// no vector-memory load is left in the epilogue. With EPI 1 every 32 x 32 block waits a full HBM round trip for
+// its residual rows with nothing else in flight (compiler-counted vmcnt(0)): [294912 x 320 x 320] 198 us vs 129 us
+// without the residual, for 31 us worth of extra bytes. The sum is rounded to bf16 once (EPI 1 rounds the GEMM
+// result, then the sum).
 template <int BN, bool GEGLU, int GSTAGES, int EPI, int MODE>
 __global__ __launch_bounds__(GNT) void gemm_persist_kernel(const DcGemmParams p) {
     static_assert(MODE == 0 || !GEGLU, "GEGLU is a plain-GEMM epilogue");
+    static_assert(EPI != 3 || !GEGLU, "the ring residual is a plain bf16 epilogue");
+    constexpr bool RES_RING = (EPI == 3);
+    constexpr int NR = RES_RING ? (GEGLU ? 0 : BN / 64) : 0;      // residual tiles per output tile: tile j = 32 columns of
+                                                                  // each wave column, [n0 + 32j, +32) | [n0 + BN/2 + 32j, +32)
     constexpr int NB = BN / 64;
     constexpr int NBX = GEGLU ? NB / 2 : NB;
     constexpr int BNOUT = GEGLU ? BN / 2 : BN;
@@ -469,7 +480,8 @@ __global__ __launch_bounds__(GNT) void gemm_persist_kernel(const DcGemmParams p)
     const int G = gridDim.x;
     const int nj = (ntiles - (int)blockIdx.x + G - 1) / G;      // output tiles of this workgroup
     const int nk = p.K / GBK;
-    const int total = nj * nk;
+    const int nkr = nk + NR;                                    // ring tiles per output tile
+    const int total = nj * nkr;
 
     const unsigned lds_base = (unsigned)(unsigned long)((lds_char_t*)smem);
     const bf16_t* const zero_ptr = reinterpret_cast<const bf16_t*>(g_zero_chunk2);
@@ -481,10 +493,12 @@ __global__ __launch_bounds__(GNT) void gemm_persist_kernel(const DcGemmParams p)
     int a_aux[A_IT];            // MODE 1: 9-bit tap validity mask; MODE 2: frame index of the row (or -1000: row >= M)
     const bf16_t* b_ptr[B_IT];
     int i_tile = 0, i_kt = 0, i_stage = 0;
+    int i_m0 = 0, i_n0 = 0;     // origin of the issue tile (ring residual)
     auto set_issue_tile = [&](int j) __attribute__((always_inline)) {
         const int logical = xcd_remap((int)blockIdx.x + j * G, ntiles);
         const int tn = logical % tiles_n, tmi = logical / tiles_n;
         const int m0 = tmi * GBM, n0 = tn * BNOUT;
+        i_m0 = m0; i_n0 = n0;
 #pragma unroll
         for (int q = 0; q < A_IT; ++q) {
             const int r = (q * 8 + wave) * 8 + srow;
@@ -530,11 +544,20 @@ __global__ __launch_bounds__(GNT) void gemm_persist_kernel(const DcGemmParams p)
         const int k0 = i_kt * GBK;
         const unsigned sa = lds_base + i_stage * STAGE;
         const unsigned sb = sa + A_BYTES;
+        const bool res_tile = RES_RING && i_kt >= nk;             // wave-uniform
 #pragma unroll
         for (int q = 0; q < A_IT; ++q) {
             if (q != part) continue;
             const bf16_t* src;
-            if (MODE == 0) {
+            if (res_tile) {
+                // residual rows of the issue tile staged like an activation tile: 16-byte chunks 0-3 = the 32 columns of
+                // block (i_kt - nk) of wave column 0, chunks 4-7 = the same block of wave column 1
+                const int r = (q * 8 + wave) * 8 + srow;
+                const int chunk = pchunk ^ ((r >> 1) & 7);
+                const int m = i_m0 + r;
+                const int col = i_n0 + (i_kt - nk) * 32 + (chunk >> 2) * (BN / 2) + (chunk & 3) * 8;
+                src = (m < p.M) ? p.residual + (size_t)m * p.ldr + col : zero_ptr;
+            } else if (MODE == 0) {
                 src = a_ptr[q] ? a_ptr[q] + k0 : zero_ptr;
             } else if (MODE == 1) {
                 const int cs = i_kt / 9;
@@ -551,12 +574,14 @@ __global__ __launch_bounds__(GNT) void gemm_persist_kernel(const DcGemmParams p)
             }
             glds16(src, sa + (q * 8 + wave) * 1024);
         }
+        if (!res_tile) {
 #pragma unroll
-        for (int q = 0; q < B_IT; ++q)
-            if ((q & 3) == part) glds16(b_ptr[q] + k0, sb + (q * 8 + wave) * 1024);
+            for (int q = 0; q < B_IT; ++q)
+                if ((q & 3) == part) glds16(b_ptr[q] + k0, sb + (q * 8 + wave) * 1024);
+        }
         if (part == 3) {
             if (++i_stage >= GSTAGES) i_stage = 0;
-            if (++i_kt >= nk) {
+            if (++i_kt >= nkr) {
                 i_kt = 0;
                 ++i_tile;
                 if (i_tile < nj) set_issue_tile(i_tile);
@@ -588,36 +613,83 @@ __global__ __launch_bounds__(GNT) void gemm_persist_kernel(const DcGemmParams p)
     for (int g = 0; g < total; ++g) {
         // tile g has landed once at most the (GSTAGES-2) younger in-flight tiles' DMAs remain outstanding
         const int younger = total - 1 - g;
-        if (GSTAGES == 4 && younger >= 2) wait_vmcnt<2 * LOADS>();
-        else if (GSTAGES >= 3 && younger >= 1) wait_vmcnt<LOADS>();
-        else wait_vmcnt<0>();
+        if (GSTAGES == 4 && younger >= 2) {
+            static_assert(GSTAGES != 4 || !RES_RING, "4-deep ring: residual tiles not counted");
+            wait_vmcnt<2 * LOADS>();
+        } else if (GSTAGES >= 3 && younger >= 1) {
+            // the one younger tile in flight is a residual tile (A_IT loads, no weight rows) or a K tile (LOADS)
+            if (RES_RING && c_kt + 1 >= nk) wait_vmcnt<A_IT>(); else wait_vmcnt<LOADS>();
+        } else {
+            wait_vmcnt<0>();
+        }
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         const bool more = g + GSTAGES - 1 < total;
         const char* sa = smem + stage * STAGE;
         const char* sb = sa + A_BYTES;
+        {
 #pragma unroll
-        for (int kk = 0; kk < GBK / 16; ++kk) {
-            if (more) issue_next_part(kk);
-            bf16x8_t xf[2], wf[NB];
+            for (int kk = 0; kk < GBK / 16; ++kk) {
+                if (more) issue_next_part(kk);
+                bf16x8_t xf[2], wf[NB];
 #pragma unroll
-            for (int mb = 0; mb < 2; ++mb)
-                xf[mb] = *reinterpret_cast<const bf16x8_t*>(sa + lds_off2(wm * 64 + mb * 32 + fr, kk * 2 + fh));
+                for (int mb = 0; mb < 2; ++mb)
+                    xf[mb] = *reinterpret_cast<const bf16x8_t*>(sa + lds_off2(wm * 64 + mb * 32 + fr, kk * 2 + fh));
 #pragma unroll
-            for (int nb = 0; nb < NB; ++nb) {
-                int brow;
-                if (GEGLU) brow = (nb < NBX ? 0 : BN / 2) + wn * (BN / 4) + (nb % NBX) * 32;
-                else brow = wn * (32 * NB) + nb * 32;
-                wf[nb] = *reinterpret_cast<const bf16x8_t*>(sb + lds_off2(brow + fr, kk * 2 + fh));
+                for (int nb = 0; nb < NB; ++nb) {
+                    int brow;
+                    if (GEGLU) brow = (nb < NBX ? 0 : BN / 2) + wn * (BN / 4) + (nb % NBX) * 32;
+                    else brow = wn * (32 * NB) + nb * 32;
+                    wf[nb] = *reinterpret_cast<const bf16x8_t*>(sb + lds_off2(brow + fr, kk * 2 + fh));
+                }
+#pragma unroll
+                for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb)
+                        acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[nb], xf[mb], acc[mb][nb], 0, 0, 0);
             }
-#pragma unroll
-            for (int mb = 0; mb < 2; ++mb)
-#pragma unroll
-                for (int nb = 0; nb < NB; ++nb)
-                    acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[nb], xf[mb], acc[mb][nb], 0, 0, 0);
         }
         if (++stage >= GSTAGES) stage = 0;
         if (++c_kt >= nk) {
+            if constexpr (RES_RING) {
+                // ---- the residual tiles of this output tile: ring tiles g+1 .. g+NB, block j of both wave columns each
+                // (static accumulator indices: a data-dependent choice of blocks makes hipcc shuffle and spill them)
+#pragma unroll
+                for (int j = 0; j < NB; ++j) {
+                    ++g;
+                    const int younger_r = total - 1 - g;
+                    if (GSTAGES >= 3 && younger_r >= 1) {
+                        if (j + 1 < NB) wait_vmcnt<A_IT>(); else wait_vmcnt<LOADS>();
+                    } else {
+                        wait_vmcnt<0>();
+                    }
+                    __builtin_amdgcn_s_barrier();
+                    asm volatile("" ::: "memory");
+                    if (g + GSTAGES - 1 < total) {
+#pragma unroll
+                        for (int kk = 0; kk < GBK / 16; ++kk) issue_next_part(kk);
+                    }
+                    const char* sr = smem + stage * STAGE;
+                    int lane_r = lane;
+                    asm volatile("" : "+v"(lane_r));             // keep these addresses out of the K loop's live set
+                    const int fr_r = lane_r & 31, fh_r = lane_r >> 5;
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        // identity weight fragment: W'[n = fr][k = 16 i + 8 fh + e] = (n == k)
+                        const int e1 = fr_r - 16 * i - 8 * fh_r;
+                        bf16x8_t idf;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) idf[e] = (e == e1) ? (short)0x3F80 : (short)0;
+#pragma unroll
+                        for (int mb = 0; mb < 2; ++mb) {
+                            const bf16x8_t xr = *reinterpret_cast<const bf16x8_t*>(
+                                sr + lds_off2(wm * 64 + mb * 32 + fr_r, (wn * 2 + i) * 2 + fh_r));
+                            acc[mb][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(idf, xr, acc[mb][j], 0, 0, 0);
+                        }
+                    }
+                    if (++stage >= GSTAGES) stage = 0;
+                }
+            }
             // ---- epilogue of output tile c_tile.
             // bf16 outputs go through a 2 KB wave-private LDS patch behind the ring, one 32 x 32 block at a time: the
             // accumulator layout (lane = row, 4 channels) would store 16-byte pieces of 32 different rows per
@@ -768,29 +840,43 @@ int launch_persist_epi_st(const DcGemmParams& p, hipStream_t stream, int grid) {
     }
     dc_note_variant(GEGLU ? (BN == 256 ? "gemm_persist_kernel<256,geglu>" : "gemm_persist_kernel<128,geglu>")
                     : MODE == 1 ? "gemm_persist_kernel<320,conv>" : MODE == 2 ? "gemm_persist_kernel<320,tconv>"
-                    : BN == 320 ? (EPI == 1 ? "gemm_persist_kernel<320,residual>" : "gemm_persist_kernel<320>")
+                    : BN == 320 ? (EPI == 1 || EPI == 3 ? "gemm_persist_kernel<320,residual>" : "gemm_persist_kernel<320>")
                     : BN == 128 ? "gemm_persist_kernel<128>" : "gemm_persist_kernel<64>");
     hipLaunchKernelGGL((gemm_persist_kernel<BN, GEGLU, ST, EPI, MODE>), dim3(grid), dim3(GNT), lds, stream, p);
     DC_CHECK_LAUNCH();
     return 0;
 }
 
-// epilogue flavour: 0 bf16, 1 bf16 + residual, 2 fp32
+// The residual can ride the LDS ring (EPI 3) when it is added to the raw GEMM result (no activation / scale between)
+// and its 64-column tiles are whole and 16-byte aligned. DC_GEMM_RING_RESIDUAL=0: epilogue loads (EPI 1), for A/B runs.
+inline bool ring_residual_ok(const DcGemmParams& p) {
+    static const int on = [] { const char* e = getenv("DC_GEMM_RING_RESIDUAL"); return e ? atoi(e) : 1; }();
+    return on && p.residual && !(p.flags & (DC_GEMM_GELU | DC_GEMM_GEGLU | DC_GEMM_OUT_F32)) && p.alpha == 1.0f &&
+           (p.N % 64 == 0) && (p.ldr % 8 == 0) && ((uintptr_t)p.residual % 16 == 0);
+}
+
+// epilogue flavour: 0 bf16, 1 bf16 + residual, 2 fp32, 3 bf16 + residual through the ring
 template <int BN, bool GEGLU>
 int launch_persist(const DcGemmParams& p, hipStream_t stream, int grid) {
     if (p.flags & DC_GEMM_OUT_F32) {
         if constexpr (GEGLU) return DC_ERR_ARG;
         else return launch_persist_epi<BN, GEGLU, 2, 0>(p, stream, grid);
     }
-    if (p.residual) return launch_persist_epi<BN, GEGLU, 1, 0>(p, stream, grid);
+    if (p.residual) {
+        if constexpr (!GEGLU) { if (ring_residual_ok(p) && p.N % BN == 0) return launch_persist_epi<BN, GEGLU, 3, 0>(p, stream, grid); }
+        return launch_persist_epi<BN, GEGLU, 1, 0>(p, stream, grid);
+    }
     return launch_persist_epi<BN, GEGLU, 0, 0>(p, stream, grid);
 }
 
 // 320-wide persistent conv3x3 (no upsampling) / temporal conv, bf16 outputs
 int launch_persist_conv320(const DcGemmParams& p, hipStream_t stream) {
-    if (p.mode == 1) return p.residual ? launch_persist_epi<320, false, 1, 1>(p, stream, 256)
+    const bool ring = ring_residual_ok(p);
+    if (p.mode == 1) return p.residual ? (ring ? launch_persist_epi<320, false, 3, 1>(p, stream, 256)
+                                               : launch_persist_epi<320, false, 1, 1>(p, stream, 256))
                                        : launch_persist_epi<320, false, 0, 1>(p, stream, 256);
-    return p.residual ? launch_persist_epi<320, false, 1, 2>(p, stream, 256)
+    return p.residual ? (ring ? launch_persist_epi<320, false, 3, 2>(p, stream, 256)
+                              : launch_persist_epi<320, false, 1, 2>(p, stream, 256))
                       : launch_persist_epi<320, false, 0, 2>(p, stream, 256);
 }
 
