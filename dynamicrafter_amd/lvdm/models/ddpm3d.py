@@ -172,6 +172,12 @@ class LatentDiffusion(DDPM):
         self.interp_mode = interp_mode
         self.fps_condition_type = fps_condition_type
         self.perframe_ae = perframe_ae
+        # `perframe_ae` is the reference's memory relief (one AutoencoderKL call per frame, ddpm3d.py:633-639,657-663).
+        # GroupNorm and the mid attention are per frame, so HOW MANY frames one launch sequence carries changes no
+        # frame's arithmetic - only how many rows each kernel sees: at 4 frames per call the 72x128 .. 144x256 levels fill
+        # the 256 CUs (16-frame clip @576x1024: encode 94 -> 74 ms, decode 161 -> 134 ms) at 6 GB of scratch.
+        # The posterior noise is still drawn per frame, in frame order, from the CPU generator (seed parity).
+        self.ae_frames_per_call = int(os.environ.get("DC_AE_FRAMES_PER_CALL", "4"))
         self.en_and_decode_n_samples_a_time = en_and_decode_n_samples_a_time
         if scale_by_std:
             self.register_buffer("scale_factor", torch.tensor(scale_factor))
@@ -229,8 +235,17 @@ class LatentDiffusion(DDPM):
         if not self.perframe_ae:
             z = self.get_first_stage_encoding(self.first_stage_model.encode(x))
         else:
-            z = torch.cat([self.get_first_stage_encoding(self.first_stage_model.encode(x[i:i + 1]))
-                           for i in range(x.shape[0])], dim=0)
+            k = max(1, self.ae_frames_per_call)
+            outs = []
+            for i in range(0, x.shape[0], k):
+                post = self.first_stage_model.encode(x[i:i + k])
+                noise = None
+                if isinstance(post, DiagonalGaussianDistribution) and not post.deterministic:
+                    n, zc, h, w = post._shape()
+                    # one CPU draw per frame, as the reference's per-frame posterior.sample() calls make them
+                    noise = torch.cat([torch.randn((1, zc, h, w)) for _ in range(n)], dim=0)
+                outs.append(self.get_first_stage_encoding(post, noise=noise))
+            z = torch.cat(outs, dim=0)
         if five:
             z = z.reshape(b, t, *z.shape[1:]).permute(0, 2, 1, 3, 4).contiguous()
         return z
@@ -244,7 +259,8 @@ class LatentDiffusion(DDPM):
         if not self.perframe_ae:
             out = self.first_stage_model.decode(inv * z, **kwargs)
         else:
-            out = torch.cat([self.first_stage_model.decode(inv * z[i:i + 1], **kwargs) for i in range(z.shape[0])], 0)
+            k = max(1, self.ae_frames_per_call)
+            out = torch.cat([self.first_stage_model.decode(inv * z[i:i + k], **kwargs) for i in range(0, z.shape[0], k)], 0)
         if five:
             out = out.reshape(b, t, *out.shape[1:]).permute(0, 2, 1, 3, 4).contiguous()
         return out

@@ -548,3 +548,24 @@ def test_bench_two_ranks_share_one_gpu_gloo():
     assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["config"]["outputs_finite"]
     assert len(out["config"]["per_rank"]) == 2 and "scatter_conditioning" in out["config"]["conditioning"]
     assert abs(out["value"] - 2 * 16 / out["config"]["clip_seconds"]) < 1e-3 * out["value"]
+
+
+def test_ae_frames_per_call_keeps_per_frame_results():
+    """`perframe_ae`: the reference calls the AutoencoderKL once per frame (ddpm3d.py:633-639,657-663); here several
+    frames ride one launch sequence (GroupNorm / mid attention are per frame, so only the rows per kernel change).
+    Same per-frame posterior noise draws, same results up to the bf16 rounding of differently tiled GEMMs."""
+    model = _tiny_lvd("inference_512_v1.0.yaml")
+    assert model.perframe_ae
+    g = torch.Generator().manual_seed(31)
+    vid = (torch.rand(1, 3, 6, 64, 96, generator=g) * 2 - 1).to(DEV)
+    outs = []
+    for k in (1, 4):
+        model.ae_frames_per_call = k
+        torch.manual_seed(77)                               # the CPU generator the posterior noise is drawn from
+        z = model.encode_first_stage(vid)
+        rec = model.decode_first_stage(z)
+        outs.append((z.clone(), rec.clone(), torch.rand(1).item()))
+    assert outs[0][2] == outs[1][2]                         # the same number of draws was consumed
+    rz, rr = rel_l2(outs[1][0], outs[0][0]), rel_l2(outs[1][1], outs[0][1])
+    print(f"\n[ae frames/call 4 vs 1] latent rel-L2 {rz:.2e}, decoded rel-L2 {rr:.2e}")
+    assert rz < 2e-2 and rr < 2e-2
