@@ -67,6 +67,11 @@ SIGNATURES = {
     "dc_add_rows": (_I, [_P, _I, _P, _I, _P, _I, _I, _I, _P]),
     "dc_vae_sample": (_I, [_P, _I, _P, _P, _I, _I, _I, _F, _P]),
     "dc_ddim_step": (_I, [C.POINTER(DcDdimParams), _P, _P, _P, _I, _P, _P, _P, _P, _I, _I, _I, _P, _P]),
+    "dc_attn_small": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F, _I, _P]),
+    "dc_attn_small_lds_bytes": (_L, [_I, _I]),
+    "dc_clip_preprocess": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, C.POINTER(_F), C.POINTER(_F), _P]),
+    "dc_patchify": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "dc_embed_tokens": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "dc_frames_to_u8": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
     "dc_mask_blend": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _L, _L, _I, _P]),
     "dc_advance_counter": (_I, [_P, _P]),

@@ -370,6 +370,51 @@ def temporal_attn(qkv, o, *, B, T, HW, heads, scale):
     return o
 
 
+def attn_small(q, k, v, o, *, batch, heads, Lq, Lk, d, scale, causal=False):
+    """Any-head-width attention (CLIP towers): q/o rows [batch*Lq, >= heads*d], k/v rows [batch*Lk, >= heads*d]."""
+    for t, n in ((q, "q"), (k, "k"), (v, "v"), (o, "o")):
+        _rows(t, n)
+    _need_rows(q, batch * Lq, heads * d, "q"); _need_rows(o, batch * Lq, heads * d, "o")
+    _need_rows(k, batch * Lk, heads * d, "k"); _need_rows(v, batch * Lk, heads * d, "v")
+    _launch("attn_small", 4.0 * batch * heads * Lq * Lk * d, 2.0 * batch * heads * d * (2 * Lq + 2 * Lk),
+            _hip.lib().dc_attn_small, _ptr(q), _ptr(k), _ptr(v), _ptr(o), q.stride(0), k.stride(0), v.stride(0), o.stride(0),
+            batch, heads, Lq, Lk, d, scale, 1 if causal else 0, stream_ptr())
+    return o
+
+
+def clip_preprocess(img, out_hw=(224, 224), antialias=True, mean=(0.48145466, 0.4578275, 0.40821073),
+                    std=(0.26862954, 0.26130258, 0.27577711)):
+    """img fp32 [N,3,H,W] in [-1,1] -> fp32 [N,3,OH,OW] (bicubic align_corners resize w/ antialias blur, CLIP mean/std)."""
+    img = img.to(torch.float32).contiguous()
+    N, Cc, H, W = img.shape
+    out = torch.empty((N, Cc, out_hw[0], out_hw[1]), dtype=torch.float32, device=img.device)
+    blur = antialias and max(H / out_hw[0], W / out_hw[1]) > 1.0
+    t0 = torch.empty_like(img) if blur else None
+    t1 = torch.empty_like(img) if blur else None
+    m3, s3 = (C.c_float * 3)(*mean), (C.c_float * 3)(*std)
+    check(_hip.lib().dc_clip_preprocess(_ptr(img), _ptr(t0), _ptr(t1), _ptr(out), N, Cc, H, W, out_hw[0], out_hw[1],
+                                        1 if antialias else 0, m3, s3, stream_ptr()), "dc_clip_preprocess")
+    return out
+
+
+def patchify(img, rows, *, patch):
+    N, Cc, H, W = img.shape
+    _need_rows(rows, N * (H // patch) * (W // patch), Cc * patch * patch, "rows")
+    check(_hip.lib().dc_patchify(_ptr(img), _ptr(rows), N, Cc, H, W, patch, rows.stride(0), stream_ptr()), "dc_patchify")
+    return rows
+
+
+def embed_tokens(tokens, table, pos, out):
+    B, L = tokens.shape
+    D = table.shape[1]
+    _need_rows(out, B * L, D, "out"); _need_rows(pos, L, D, "pos")
+    if out.stride(0) != D or table.stride(0) != D or pos.stride(0) != D:
+        raise ValueError("embed_tokens: dense rows expected")
+    check(_hip.lib().dc_embed_tokens(_ptr(tokens), _ptr(table), _ptr(pos), _ptr(out), B, L, D, table.shape[0], stream_ptr()),
+          "dc_embed_tokens")
+    return out
+
+
 def gemv_small(x, pw, out, *, act_in=0, act_out=0, accumulate=False):
     """x [M<=8, K] fp32, out [M, N] fp32."""
     if x.shape[0] > 8 or x.shape[1] < pw.K or out.shape[0] < x.shape[0] or out.shape[1] < pw.N:

@@ -174,6 +174,35 @@ int dc_ddim_step(const DcDdimParams* p, const float* e_cond, const float* e_unco
                  const float* x, const float* noise, float* x_prev, float* pred_x0, int B, int C, int THW,
                  float* workspace, void* stream);
 
+/* ---- conditioning encoders (once per clip) ---------------------------------------------------- */
+
+/* Multi-head attention for any (even) head width d <= 256 and Lk <= 1024, optional causal mask (key j visible to query
+ * i iff j <= i): o[b, i, h*d..] = softmax_j(scale * q[b,i,h] . k[b,j,h]) v[b,j,h]. q/o rows [B*Lq, >= heads*d], k/v rows
+ * [B*Lk, >= heads*d] (bf16, row strides ld*). Needs dc_attn_small_lds_bytes(Lk, d) <= 160 KiB.
+ * replaces open_clip's ResidualAttentionBlock attention (nn.MultiheadAttention, 16 heads x 80 in the ViT-H/14 vision
+ * tower, 16 x 64 causal in the text tower) as driven by lvdm/modules/encoders/condition.py:216-234, 364-368 */
+int dc_attn_small(const uint16_t* q, const uint16_t* k, const uint16_t* v, uint16_t* o, int ldq, int ldk, int ldv, int ldo,
+                  int B, int heads, int Lq, int Lk, int d, float scale, int causal, void* stream);
+int64_t dc_attn_small_lds_bytes(int Lk, int d);
+
+/* CLIP image preprocessing: img[N][3][H][W] fp32 in [-1,1] -> out[N][3][OH][OW] fp32 = normalize((resize(img)+1)/2).
+ * resize = kornia.geometry.resize(bicubic, align_corners=True, antialias): when downscaling and antialias != 0, a
+ * separable Gaussian blur (sigma = max((factor-1)/2, 0.001), ks = int(max(4 sigma, 3)) made odd, reflect borders) first;
+ * tmp0/tmp1: N*3*H*W floats each (only used with the blur). mean3/std3: HOST pointers to 3 floats.
+ * replaces FrozenOpenCLIPImageEmbedderV2.preprocess lvdm/modules/encoders/condition.py:322-330 */
+int dc_clip_preprocess(const float* img, float* tmp0, float* tmp1, float* out, int N, int C, int H, int W, int OH, int OW,
+                       int antialias, const float* mean3, const float* std3, void* stream);
+
+/* Non-overlapping p x p patches of img[N][C][H][W] fp32 -> bf16 rows [N*(H/p)*(W/p)][kpad], column c*p*p + py*p + px
+ * (the ViT patch embedding conv1 as a plain GEMM; zero columns up to kpad, kpad % 8 == 0).
+ * replaces model.visual.conv1 lvdm/modules/encoders/condition.py:349-351 */
+int dc_patchify(const float* img, uint16_t* rows, int N, int C, int H, int W, int p, int kpad, void* stream);
+
+/* out[b*L + i][:] = table[tokens[b][i]][:] + pos[i][:] (bf16 rows of width D; token ids clamped to the vocabulary).
+ * replaces token_embedding + positional_embedding lvdm/modules/encoders/condition.py:216-217 */
+int dc_embed_tokens(const int64_t* tokens, const uint16_t* table, const uint16_t* pos, uint16_t* out, int B, int L, int D,
+                    int vocab, void* stream);
+
 /* Decoded clips video[N][C][T][H][W] fp32 in [-1,1] -> display frames out[T][H][N*W][C] uint8: clamp, (v+1)/2, *255,
  * truncation; the N clips of a batch side by side (torchvision make_grid(nrow=N, padding=0)).
  * replaces scripts/evaluation/inference.py:127-137 (save_results) / :151-160 (save_results_seperate, N = 1),

@@ -88,10 +88,21 @@ def test_released_yaml_instantiates_with_reference_keys():
     digest = sorted(f"{k}:{'x'.join(map(str, v.shape))}" for k, v in unet.state_dict().items())
     assert digest == [str(s) for s in g["key_digest"]]
     assert sum(p.numel() for p in unet.parameters()) == 1438854980
-    # conditioner placeholders construct but refuse to run
-    enc = instantiate_from_config(cfg["model"]["params"]["cond_stage_config"])
-    with pytest.raises(NotImplementedError):
-        enc(["a prompt"])
+    # the OpenCLIP towers are built from the released YAML entries; their state_dict keys are the open_clip CLIP object's
+    # (text wrapper: no `visual.*`; vision wrapper: no `transformer.*`) - what `cond_stage_model.*` / `embedder.*` of a
+    # released checkpoint hold. Built on the meta device here (2 x ~0.7 B parameters).
+    from oracle import clip as oclip
+    with torch.device("meta"):
+        enc = instantiate_from_config(cfg["model"]["params"]["cond_stage_config"])
+        emb = instantiate_from_config(cfg["model"]["params"]["img_cond_stage_config"])
+    assert {k: tuple(v.shape) for k, v in enc.state_dict().items()} == oclip.clip_text_shapes()
+    assert {k: tuple(v.shape) for k, v in emb.state_dict().items()} == oclip.clip_vision_shapes()
+    assert enc.layer == "penultimate" and enc.layer_idx == 1
+    assert sum(v.numel() for k, v in emb.state_dict().items() if "visual" in k) == 632076800       # ViT-H/14 vision tower
+    with pytest.raises(FileNotFoundError):                       # no BPE vocabulary in this image: loud, not silent
+        enc.tokenize(["a prompt"])
+    with pytest.raises(RuntimeError):                            # and no CPU fallback
+        enc(torch.zeros(1, 77, dtype=torch.long))
     # reference YAML content is unchanged
     ref = os.path.join("/root/reference/configs/inference_1024_v1.0.yaml")
     if os.path.exists(ref):

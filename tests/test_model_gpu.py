@@ -569,3 +569,46 @@ def test_ae_frames_per_call_keeps_per_frame_results():
     rz, rr = rel_l2(outs[1][0], outs[0][0]), rel_l2(outs[1][1], outs[0][1])
     print(f"\n[ae frames/call 4 vs 1] latent rel-L2 {rz:.2e}, decoded rel-L2 {rr:.2e}")
     assert rz < 2e-2 and rr < 2e-2
+
+
+TINY_CLIP = dict(embed_dim=64, vision=dict(image_size=56, layers=3, width=320, heads=4, patch_size=14, mlp_ratio=4.0),
+                 text=dict(context_length=77, vocab_size=300, width=128, heads=2, layers=4, mlp_ratio=4.0))
+
+
+@pytest.mark.parametrize("arch", ["tiny", "ViT-H-14"])
+def test_openclip_towers_vs_oracle(arch):
+    """the OpenCLIP text tower (causal, penultimate layer, ln_final) and vision tower (bicubic-224
+    preprocessing, patch GEMM, 16 heads x 80) on the HIP path against oracle/clip.py with recipe weights - a narrow
+    configuration and the released ViT-H/14 widths/depths. (The oracle itself is parity-unpinned against open_clip,
+    which is not in the image; see oracle/clip.py.)"""
+    from dynamicrafter_amd.lvdm.modules.encoders.condition import (ARCHS, FrozenOpenCLIPEmbedder,
+                                                                    FrozenOpenCLIPImageEmbedderV2)
+    from oracle import clip as oclip
+    from oracle.weights import fill_state_dict
+    a = TINY_CLIP if arch == "tiny" else ARCHS[arch]
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    txt = FrozenOpenCLIPEmbedder(arch=a, layer="penultimate")
+    sd = fill_state_dict({k: tuple(v.shape) for k, v in txt.state_dict().items()}, seed=15)
+    sd["model.positional_embedding"] = sd["model.positional_embedding"] * 0.02 / sd["model.positional_embedding"].std()
+    txt.load_state_dict(sd, strict=True)
+    txt.to(DEV)
+    g = torch.Generator().manual_seed(8)
+    tokens = torch.randint(0, a["text"]["vocab_size"], (2, 77), generator=g)
+    y = txt(tokens.to(DEV))
+    ref = oclip.text_forward(sd, tokens, heads=a["text"]["heads"], layer_idx=1)
+    r, c = rel_l2(y, ref), cosine(y, ref)
+    print(f"\n[openclip {arch}] text tower rel-L2 {r:.3e} cosine {c:.6f}")
+    assert tuple(y.shape) == (2, 77, a["text"]["width"]) and r < 3e-2 and c > 0.999
+    del txt
+    vis = FrozenOpenCLIPImageEmbedderV2(arch=a)
+    sd = fill_state_dict({k: tuple(v.shape) for k, v in vis.state_dict().items()}, seed=16)
+    vis.load_state_dict(sd, strict=True)
+    vis.to(DEV)
+    img = torch.rand(2, 3, 320, 512, generator=g) * 2 - 1
+    y = vis(img.to(DEV))
+    sz = (a["vision"]["image_size"],) * 2
+    ref = oclip.vision_forward(sd, img, heads=a["vision"]["heads"], size=sz)
+    r, c = rel_l2(y, ref), cosine(y, ref)
+    print(f"[openclip {arch}] vision tower rel-L2 {r:.3e} cosine {c:.6f}")
+    n_tok = (a["vision"]["image_size"] // a["vision"]["patch_size"]) ** 2 + 1
+    assert tuple(y.shape) == (2, n_tok, a["vision"]["width"]) and r < 3e-2 and c > 0.999

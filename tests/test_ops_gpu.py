@@ -561,3 +561,46 @@ def test_conv_dispatch_fuzz(ops, n, C, Co, H, W, stride, seed):
     ops.gemm(rows, pw, out, conv=dict(IH=H, IW=W, OH=OH, OW=OW, stride=stride, pad=1, ups=0))
     want = ref.permute(0, 2, 3, 1).reshape(-1, Co)
     assert rel_l2(out, want) < 4e-3, ops._hip.lib().dc_gemm_last_variant().decode()
+
+
+@pytest.mark.parametrize("B,heads,L,d,causal", [(2, 16, 257, 80, False), (3, 16, 77, 64, True), (1, 3, 40, 6, True),
+                                                (1, 2, 500, 64, False)])
+def test_attn_small_vs_torch(ops, B, heads, L, d, causal):
+    """dc_attn_small (CLIP towers: any head width, optional causal mask) against fp32 softmax attention."""
+    g = torch.Generator().manual_seed(5)
+    D = heads * d
+    Dp = (D + 7) // 8 * 8
+    qkv = (torch.randn(B * L, 3 * Dp, generator=g)).to(torch.bfloat16).to(DEV)
+    q, k, v = qkv[:, :D], qkv[:, Dp:Dp + D], qkv[:, 2 * Dp:2 * Dp + D]
+    o = torch.zeros(B * L, Dp, dtype=torch.bfloat16, device=DEV)
+    ops.attn_small(q, k, v, o, batch=B, heads=heads, Lq=L, Lk=L, d=d, scale=d ** -0.5, causal=causal)
+    sp = lambda t: t.float().cpu().reshape(B, L, heads, d).transpose(1, 2)
+    s = (sp(q) * d ** -0.5) @ sp(k).transpose(-1, -2)
+    if causal:
+        s = s + torch.full((L, L), float("-inf")).triu_(1)
+    ref = (s.softmax(-1) @ sp(v)).transpose(1, 2).reshape(B * L, D)
+    assert rel_l2(o[:, :D], ref) < 6e-3
+
+
+def test_clip_preprocess_patchify_embed_vs_oracle(ops):
+    from oracle import clip as oclip
+    g = torch.Generator().manual_seed(6)
+    for shape in ((2, 3, 320, 512), (1, 3, 576, 1024), (1, 3, 224, 224), (1, 3, 200, 180)):
+        img = (torch.rand(*shape, generator=g) * 2 - 1)
+        out = ops.clip_preprocess(img.to(DEV))
+        ref = oclip.preprocess(img)
+        assert tuple(out.shape) == tuple(ref.shape)
+        assert ((out.cpu() - ref).abs().max() / ref.abs().max()).item() < 2e-5, shape
+    img = torch.randn(2, 3, 28, 42, generator=g)
+    rows = torch.empty(2 * 2 * 3, 640, dtype=torch.bfloat16, device=DEV)
+    ops.patchify(img.to(DEV), rows, patch=14)
+    ref = torch.nn.functional.unfold(img, 14, stride=14).transpose(1, 2).reshape(12, 588)
+    assert torch.equal(rows[:, :588].float().cpu(), ref.to(torch.bfloat16).float())
+    assert float(rows[:, 588:].float().abs().max()) == 0.0
+    table = torch.randn(50, 64, generator=g).to(torch.bfloat16)
+    pos = torch.randn(7, 64, generator=g).to(torch.bfloat16)
+    tok = torch.randint(0, 50, (3, 7), generator=g)
+    out = torch.empty(21, 64, dtype=torch.bfloat16, device=DEV)
+    ops.embed_tokens(tok.to(DEV), table.to(DEV), pos.to(DEV), out)
+    ref = (table.float()[tok] + pos.float()).reshape(21, 64).to(torch.bfloat16)
+    assert torch.equal(out.cpu(), ref)

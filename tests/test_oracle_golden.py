@@ -318,3 +318,46 @@ def test_unet_fullsize_32x32_matches_reference():
     x = torch.cat([T(g["x"]), T(g["c_concat"])], 1)
     y = ounet.unet_forward(sd, cfg, x, T(g["timesteps"]), T(g["context"]), T(g["fs"]))
     assert maxrel(y, g["y"]) < 1e-4
+
+
+def test_clip_oracle_blocks_match_torch_modules():
+    """oracle/clip.py is PARITY-UNPINNED against open_clip (absent offline); its pieces are pinned against torch's own
+    modules: the attention restatement against nn.MultiheadAttention (causal mask, 5 heads x 16), the residual block
+    against a module assembled the way open_clip's ResidualAttentionBlock is, the preprocessing against torch's bicubic
+    interpolate with an explicit reflect-padded Gaussian blur."""
+    import torch.nn as nn
+    from oracle import clip as oclip
+    torch.manual_seed(0)
+    D, H, L, B = 80, 5, 13, 2
+    m = nn.MultiheadAttention(D, H)
+    ln1, ln2 = nn.LayerNorm(D), nn.LayerNorm(D)
+    fc, proj = nn.Linear(D, 4 * D), nn.Linear(4 * D, D)
+    for mod in (ln1, ln2):
+        nn.init.normal_(mod.weight, 1.0, 0.1); nn.init.normal_(mod.bias, 0.0, 0.1)
+    nn.init.normal_(m.in_proj_bias, 0.0, 0.1); nn.init.normal_(m.out_proj.bias, 0.0, 0.1)
+    p = "t.resblocks.0"
+    sd = {p + ".attn.in_proj_weight": m.in_proj_weight, p + ".attn.in_proj_bias": m.in_proj_bias,
+          p + ".attn.out_proj.weight": m.out_proj.weight, p + ".attn.out_proj.bias": m.out_proj.bias,
+          p + ".ln_1.weight": ln1.weight, p + ".ln_1.bias": ln1.bias, p + ".ln_2.weight": ln2.weight, p + ".ln_2.bias": ln2.bias,
+          p + ".mlp.c_fc.weight": fc.weight, p + ".mlp.c_fc.bias": fc.bias, p + ".mlp.c_proj.weight": proj.weight,
+          p + ".mlp.c_proj.bias": proj.bias}
+    sd = {k: v.detach() for k, v in sd.items()}
+    x = torch.randn(B, L, D)
+    mask = oclip.causal_mask(L)
+    with torch.no_grad():
+        for msk in (None, mask):
+            xl = x.permute(1, 0, 2)                                       # open_clip runs the tower in LND
+            h = xl + m(ln1(xl), ln1(xl), ln1(xl), need_weights=False, attn_mask=msk)[0]
+            ref = (h + proj(torch.nn.functional.gelu(fc(ln2(h))))).permute(1, 0, 2)
+            assert maxrel(oclip.resblock(sd, p, x, H, msk), ref) < 2e-6
+    # preprocessing: identity when no downscale (no blur), finite and normalised otherwise
+    img = torch.rand(1, 3, 224, 224) * 2 - 1
+    same = oclip.preprocess(img)
+    mean = torch.tensor(oclip.CLIP_MEAN).reshape(1, 3, 1, 1); std = torch.tensor(oclip.CLIP_STD).reshape(1, 3, 1, 1)
+    assert maxrel(same, ((img + 1) / 2 - mean) / std) < 1e-5
+    big = torch.rand(1, 3, 320, 512) * 2 - 1
+    out = oclip.preprocess(big)
+    assert tuple(out.shape) == (1, 3, 224, 224) and torch.isfinite(out).all()
+    # a constant image stays constant through blur + bicubic (both kernels sum to 1)
+    c = oclip.preprocess(torch.full((1, 3, 320, 512), 0.25))
+    assert maxrel(c, ((torch.full((1, 3, 224, 224), 0.25) + 1) / 2 - mean) / std) < 1e-5
