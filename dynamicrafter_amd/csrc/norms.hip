@@ -1,9 +1,11 @@
 // GroupNorm(+SiLU) and LayerNorm over channels-last bf16 rows; fp32 statistics. HBM-bound kernels:
 // 16-byte loads/stores per lane, each row read twice (stats pass + apply pass) and written once.
 //
-// GroupNorm is three launches: partial sums per (instance, row-chunk, group) -> finalize (mean, rstd) per
+// GroupNorm is three launches: partial moments per (instance, row-chunk, group) -> finalize (mean, rstd) per
 // (instance, group) -> normalise*affine(+SiLU). All reductions have a fixed order: results are bitwise
-// reproducible run to run.
+// reproducible run to run. The moments are (mean, M2 = sum of squared deviations), accumulated per thread around its
+// first sample and merged with Chan's parallel update - not E[x^2] - mean^2, whose cancellation error ~1e-7 mean^2/var
+// reaches percent level on channels with a large DC offset (up to 2.4 M elements per group at the AE's 576x1024 levels).
 //   reference: GroupNormSpecific lvdm/basics.py:76-87 (eps 1e-5, fp32), nn.GroupNorm(32, C) in
 //   TemporalConvBlock openaimodel3d.py:256-265 (5-D: statistics span T*H*W), transformer norms
 //   attention.py:265,331 (eps 1e-6), AE Normalize ae_modules.py:15-16 (eps 1e-6) + swish :10-12.
@@ -34,11 +36,16 @@ __global__ void gn_partial_kernel(const bf16_t* __restrict__ x, int ldx, int C, 
     const int r_begin = chunk * rows_per_chunk;
     int r_end = r_begin + rows_per_chunk;
     if (r_end > rows_per_inst) r_end = rows_per_inst;
-    float s[8], ss[8];
+    float s[8], ss[8], K[8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) { s[e] = 0.f; ss[e] = 0.f; }
+    for (int e = 0; e < 8; ++e) { s[e] = 0.f; ss[e] = 0.f; K[e] = 0.f; }
     const bf16_t* base = x + (size_t)inst * rows_per_inst * ldx + v * 8;
     int r = r_begin + ro;
+    const int n_t = r < r_end ? (r_end - r + rpp - 1) / rpp : 0;      // samples per channel of this thread
+    if (n_t > 0) {                                                      // shift = the thread's first sample of each channel
+        const uint4 raw = *reinterpret_cast<const uint4*>(base + (size_t)r * ldx);
+        unpack_bf8(raw, K);
+    }
     // eight independent 16-byte loads in flight per lane (HBM latency, not issue rate, bounds this pass)
     for (; r + 7 * rpp < r_end; r += 8 * rpp) {
         uint4 raw[8];
@@ -49,7 +56,7 @@ __global__ void gn_partial_kernel(const bf16_t* __restrict__ x, int ldx, int C, 
             float f[8];
             unpack_bf8(raw[u], f);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) { s[e] += f[e]; ss[e] += f[e] * f[e]; }
+            for (int e = 0; e < 8; ++e) { const float d = f[e] - K[e]; s[e] += d; ss[e] += d * d; }
         }
     }
     for (; r < r_end; r += rpp) {
@@ -57,26 +64,37 @@ __global__ void gn_partial_kernel(const bf16_t* __restrict__ x, int ldx, int C, 
         float f[8];
         unpack_bf8(raw, f);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { s[e] += f[e]; ss[e] += f[e] * f[e]; }
+        for (int e = 0; e < 8; ++e) { const float d = f[e] - K[e]; s[e] += d; ss[e] += d * d; }
     }
-    float* sm_s = sm;
-    float* sm_q = sm + rpp * C;
+    // per (row slot, channel): mean and M2 of the thread's n_t samples
+    float* sm_s = sm;                 // means
+    float* sm_q = sm + rpp * C;       // M2
+    const float inv_n = n_t > 0 ? 1.0f / (float)n_t : 0.f;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-        sm_s[ro * C + v * 8 + e] = s[e];
-        sm_q[ro * C + v * 8 + e] = ss[e];
+        sm_s[ro * C + v * 8 + e] = K[e] + s[e] * inv_n;
+        sm_q[ro * C + v * 8 + e] = ss[e] - s[e] * s[e] * inv_n;
     }
     __syncthreads();
     if ((int)threadIdx.x < groups) {
         const int cpg = C / groups;
         const int g = threadIdx.x;
-        float a = 0.f, b = 0.f;
-        for (int rr = 0; rr < rpp; ++rr)
+        // Chan merge in a fixed order: row slots outer, channels inner
+        float n = 0.f, mean = 0.f, m2 = 0.f;
+        for (int rr = 0; rr < rpp; ++rr) {
+            const int first = r_begin + rr;
+            const float nb = first < r_end ? (float)((r_end - first + rpp - 1) / rpp) : 0.f;
+            if (nb == 0.f) continue;
             for (int c = 0; c < cpg; ++c) {
-                a += sm_s[rr * C + g * cpg + c];
-                b += sm_q[rr * C + g * cpg + c];
+                const float mb = sm_s[rr * C + g * cpg + c], qb = sm_q[rr * C + g * cpg + c];
+                const float nn = n + nb;
+                const float delta = mb - mean;
+                mean += delta * (nb / nn);
+                m2 += qb + delta * delta * (n * nb / nn);
+                n = nn;
             }
-        partial[((size_t)inst * chunks + chunk) * groups + g] = make_float2(a, b);
+        }
+        partial[((size_t)inst * chunks + chunk) * groups + g] = make_float2(mean, m2);
     }
 }
 
@@ -84,17 +102,35 @@ __global__ void gn_partial_kernel(const bf16_t* __restrict__ x, int ldx, int C, 
 // sums, then a fixed shuffle tree) -> (mean, rstd). One workgroup per instance took 12 us on the 5-D norms (2 instances
 // x 1024 chunks); spread over groups it is launch-latency-bound.
 __global__ __launch_bounds__(64) void gn_finalize_kernel(const float2* __restrict__ partial, int chunks, int groups,
-                                                         float count, float eps, float2* __restrict__ stats) {
+                                                         int rows_per_inst, int rows_per_chunk, int cpg, float eps,
+                                                         float2* __restrict__ stats) {
     const int g = blockIdx.x, inst = blockIdx.y;
-    float a = 0.f, b = 0.f;
+    float n = 0.f, mean = 0.f, m2 = 0.f;
     for (int c = threadIdx.x; c < chunks; c += 64) {
         const float2 p = partial[((size_t)inst * chunks + c) * groups + g];
-        a += p.x; b += p.y;
+        int rows = rows_per_inst - c * rows_per_chunk;
+        if (rows > rows_per_chunk) rows = rows_per_chunk;
+        const float nb = (float)rows * (float)cpg;
+        const float nn = n + nb;
+        const float delta = p.x - mean;
+        mean += delta * (nb / nn);
+        m2 += p.y + delta * delta * (n * nb / nn);
+        n = nn;
     }
-    a = wave_sum(a); b = wave_sum(b);
+    // fixed shuffle tree of Chan merges (lanes without chunks carry n = 0)
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float nb = __shfl_xor(n, o, 64), mb = __shfl_xor(mean, o, 64), qb = __shfl_xor(m2, o, 64);
+        const float nn = n + nb;
+        if (nn > 0.f) {                                  // only lane 0's merge chain reaches the result; its order is fixed
+            const float delta = mb - mean;
+            mean += delta * (nb / nn);
+            m2 += qb + delta * delta * (n * nb / nn);
+            n = nn;
+        }
+    }
     if (threadIdx.x == 0) {
-        const float mean = a / count;
-        float var = b / count - mean * mean;
+        float var = m2 / n;
         if (var < 0.f) var = 0.f;
         stats[(size_t)inst * groups + g] = make_float2(mean, rsqrtf(var + eps));
     }
@@ -241,9 +277,8 @@ extern "C" int dc_groupnorm(const uint16_t* x, int ldx, uint16_t* y, int ldy, co
     hipLaunchKernelGGL(gn_partial_kernel, dim3(g.chunks, n_inst), dim3(threads), lds, stream, x, ldx, C, groups,
                        rows_per_inst, g.rows_per_chunk, g.chunks, vecs, rpp, partial);
     DC_CHECK_LAUNCH();
-    const float count = (float)rows_per_inst * (float)(C / groups);
-    hipLaunchKernelGGL(gn_finalize_kernel, dim3(groups, n_inst), dim3(64), 0, stream, partial, g.chunks, groups, count, eps,
-                       stats);
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(groups, n_inst), dim3(64), 0, stream, partial, g.chunks, groups, rows_per_inst,
+                       g.rows_per_chunk, C / groups, eps, stats);
     DC_CHECK_LAUNCH();
     hipLaunchKernelGGL(gn_apply_kernel, dim3(g.chunks, n_inst), dim3(threads), 0, stream, x, ldx, y, ldy, gamma, beta,
                        C, groups, rows_per_inst, g.rows_per_chunk, vecs, rpp, silu, stats);

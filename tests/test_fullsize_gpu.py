@@ -14,8 +14,7 @@ attention L = 9 216, GroupNorm over 147 456 (5-D) and 589 824 (AE) rows per inst
 Stated tolerances (bf16 storage and MFMA inputs, fp32 accumulate; oracle/reference fp32) - set at <= 2x the values
 measured on MI355X, which every test prints:
   UNet forward, each branch    rel-L2 <= 3e-2, cosine >= 0.9997   (measured 1.6e-2 / 0.99988 at 16x72x128)
-  fused DDIM update (x_prev)   rel-L2 <= 1e-1 of the oracle's update from the oracle's own model outputs (CFG 7.5
-                               amplifies the branch difference's error)
+  fused DDIM update (x_prev)   rel-L2 <= 2.3e-2 of the oracle's update (measured 1.1e-2 at 16x72x128, first step)
   AE moments / latent / decode rel-L2 <= 3e-2 / 1e-2 / 2.7e-2   (measured 1.5e-2 / 5.0e-3 / 1.3e-2 on a 576x1024 frame;
                                the moments include the wide-range logvar half, the sampled latent does not)
   oracle vs reference fixture  max-rel <= 1e-4 (fp32 both, different summation orders over K up to 23 040)
@@ -36,7 +35,7 @@ G = os.path.join(HERE, "golden")
 CFG_DIR = os.path.join(HERE, "..", "dynamicrafter_amd", "configs")
 
 UNET_TOL, UNET_COS = 3e-2, 0.9997
-STEP_TOL = 1e-1
+STEP_TOL = 2.3e-2
 AE_MOM_TOL, AE_Z_TOL, AE_DEC_TOL = 3e-2, 1e-2, 2.7e-2
 
 

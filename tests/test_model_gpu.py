@@ -1,10 +1,12 @@
 """Model-level parity on the GPU: the HIP-backed lvdm classes against (a) golden vectors captured from the
 reference (tests/golden) and (b) the CPU oracle on the same seeded inputs.
 
-Stated tolerances (bf16 storage, fp32 accumulate; oracle/reference are fp32):
-  whole UNet forward      rel-L2 <= 3e-2 and cosine >= 0.999
-  AutoencoderKL enc/dec   rel-L2 <= 3e-2
-  10-step DDIM trajectory rel-L2 <= 1e-1
+Stated tolerances (bf16 storage, fp32 accumulate; oracle/reference are fp32), each <= 2x the value measured on MI355X
+(every test prints what it measures):
+  whole UNet forward      rel-L2 <= 3e-2 and cosine >= 0.999          (measured 1.7e-2 / 0.99986)
+  AutoencoderKL enc/dec   rel-L2 <= 3e-2                               (measured 1.5e-2 moments, 1.7e-2 decode)
+  10-step DDIM trajectory rel-L2 <= 8.5e-2                             (measured 3.1e-2 / 4.2e-2)
+  50-step trajectory      rel-L2 <= 4e-2                               (measured 2.0e-2)
   fused DDIM step (fp32)  max-rel <= 1e-5
 """
 import os
@@ -188,7 +190,7 @@ def test_ddim_trajectory_vs_reference(tag, disc, eta, gr, extra):
         r = rel_l2(samples, g["samples"])
         if not use_graph:
             print(f"\n[trajectory {tag}] 10 steps vs reference rel-L2 {r:.3e}")
-        assert r < 1e-1
+        assert r < 8.5e-2                                  # measured 3.1e-2 (256 cfg) / 4.2e-2 (512 cfg, eta=1)
         outs.append(samples.clone())
     assert torch.equal(outs[0], outs[1])          # graph replay == eager launches, bit for bit
     assert torch.equal(x_T, T(g["x_T"]))          # inputs are not mutated
@@ -365,7 +367,7 @@ def test_image_guided_synthesis_vs_reference(tag, cname):
     assert torch.isfinite(out).all()
     r = rel_l2(out, g["out"])
     print(f"\n[harness {tag}] decoded clip vs reference rel-L2 {r:.3e}")
-    assert r < 1e-1
+    assert r < {"a": 1e-1, "b": 3e-2, "c": 1e-1}[tag]       # measured 6.3e-2 / 1.4e-2 / 7.3e-2
     assert torch.equal(videos, T(g["videos"]))       # inputs are not mutated
 
 
@@ -598,7 +600,7 @@ def test_openclip_towers_vs_oracle(arch):
     ref = oclip.text_forward(sd, tokens, heads=a["text"]["heads"], layer_idx=1)
     r, c = rel_l2(y, ref), cosine(y, ref)
     print(f"\n[openclip {arch}] text tower rel-L2 {r:.3e} cosine {c:.6f}")
-    assert tuple(y.shape) == (2, 77, a["text"]["width"]) and r < 3e-2 and c > 0.999
+    assert tuple(y.shape) == (2, 77, a["text"]["width"]) and r < 2.5e-2 and c > 0.9997    # measured 1.2e-2 (ViT-H/14)
     del txt
     vis = FrozenOpenCLIPImageEmbedderV2(arch=a)
     sd = fill_state_dict({k: tuple(v.shape) for k, v in vis.state_dict().items()}, seed=16)
@@ -611,4 +613,4 @@ def test_openclip_towers_vs_oracle(arch):
     r, c = rel_l2(y, ref), cosine(y, ref)
     print(f"[openclip {arch}] vision tower rel-L2 {r:.3e} cosine {c:.6f}")
     n_tok = (a["vision"]["image_size"] // a["vision"]["patch_size"]) ** 2 + 1
-    assert tuple(y.shape) == (2, n_tok, a["vision"]["width"]) and r < 3e-2 and c > 0.999
+    assert tuple(y.shape) == (2, n_tok, a["vision"]["width"]) and r < 2.5e-2 and c > 0.9997   # measured 1.2e-2

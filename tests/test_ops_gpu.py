@@ -134,6 +134,20 @@ def test_groupnorm(ops, Cc, n_inst, rpi, silu, eps):
     assert rel_l2(y, ref) < 4e-3
 
 
+@pytest.mark.parametrize("offset,std", [(50.0, 1.0), (300.0, 0.5), (-20.0, 3.0)])
+def test_groupnorm_large_dc_offset(ops, offset, std):
+    """Channels with a large mean (real-checkpoint activations, AE high-resolution levels): the statistics are shifted
+    moments merged with Chan's update, not E[x^2] - mean^2. Reference: fp64 group_norm of the same bf16 samples."""
+    Cc, n_inst, rpi = 320, 2, 40000
+    x = bf(rnd(n_inst * rpi, Cc, seed=4) * std + offset)
+    g = 1 + 0.2 * rnd(Cc, seed=2); b = 0.3 * rnd(Cc, seed=3)
+    y = torch.empty_like(x, device=DEV)
+    ops.groupnorm(x.to(DEV), y, g.to(DEV), b.to(DEV), groups=32, n_inst=n_inst, rows_per_inst=rpi, eps=1e-5, silu=False)
+    xr = x.double().reshape(n_inst, rpi, Cc).permute(0, 2, 1)
+    ref = F.group_norm(xr, 32, g.double(), b.double(), 1e-5).permute(0, 2, 1).reshape(-1, Cc)
+    assert rel_l2(y, ref) < 4e-3
+
+
 @pytest.mark.parametrize("Cc", [320, 512, 640, 1280, 64])
 def test_layernorm(ops, Cc):
     R = 301
@@ -590,7 +604,7 @@ def test_clip_preprocess_patchify_embed_vs_oracle(ops):
         out = ops.clip_preprocess(img.to(DEV))
         ref = oclip.preprocess(img)
         assert tuple(out.shape) == tuple(ref.shape)
-        assert ((out.cpu() - ref).abs().max() / ref.abs().max()).item() < 2e-5, shape
+        assert ((out.cpu() - ref).abs().max() / ref.abs().max()).item() < 1e-4, shape      # fp32 both; __expf taps, summation order
     img = torch.randn(2, 3, 28, 42, generator=g)
     rows = torch.empty(2 * 2 * 3, 640, dtype=torch.bfloat16, device=DEV)
     ops.patchify(img.to(DEV), rows, patch=14)
