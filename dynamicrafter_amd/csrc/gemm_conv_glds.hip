@@ -440,6 +440,126 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const DcGemmParams p
 // already older than the hand-counted window, so each counted wait can only over-wait, never under-wait.
 // MODE as in gemm_conv_glds_kernel: 0 plain rows, 1 conv3x3 (no upsampling), 2 temporal 3-tap conv. The short-K convs
 // (level-0/1 ResBlock and TemporalConvBlock convs: 15-90 K tiles) gain from the same cross-tile pipelining.
+// Epilogue of one 256 x BN output tile of the persistent kernels, straight from the accumulators (8 waves as 4 x 2, each
+// 64 rows x BNOUT/2 columns): bias / GEGLU / GELU / per-row-group vector / alpha in the accumulator layout, then - for bf16
+// outputs - through a 2 KB wave-private LDS patch `ebuf` one 32 x 32 block at a time: the accumulator layout (lane = row,
+// 4 channels) would store 16-byte pieces of 32 different rows per instruction, and those scattered stores cost as
+// much as the whole K loop of a short-K GEMM ([294912 x 320 x 320]: 143 us with them, 66 us without). Read back
+// row-major, a lane owns 8 consecutive channels and one instruction moves 16 rows x 64 contiguous bytes. The residual
+// (EPI 1) is fetched in the same row-major pattern. LDS operations of one wave execute in order: the patch needs no
+// barrier. (Tried and dropped: packing the whole tile first, taking the next K tile's wait and barrier before the
+// stores and loading all residual blocks ahead of the first store - slower.)
+template <int BN, bool GEGLU, int EPI>
+__device__ __forceinline__ void persist_epilogue(f32x16_t (&acc)[2][BN / 64], const DcGemmParams& p, int m0, int n0, int n_out,
+                                                 int wm, int wn, int lane, char* ebuf) {
+    constexpr int NB = BN / 64;
+    constexpr int NBX = GEGLU ? NB / 2 : NB;
+    constexpr int BNOUT = GEGLU ? BN / 2 : BN;
+    constexpr int WCOLS = BNOUT / 2;
+    // lane coordinates re-derived behind an opaque move: otherwise every address below is loop-invariant, gets
+    // hoisted out of the K loop and is kept alive (spilled) across it
+    int lane_e = lane;
+    asm volatile("" : "+v"(lane_e));
+    const int fr_e = lane_e & 31, fh_e = lane_e >> 5;
+
+    // bias / GEGLU / GELU / per-row-group vector / alpha, in the accumulator layout
+    auto finish = [&](int mb, int nb, int q) __attribute__((always_inline)) -> float4 {
+        const int m = m0 + wm * 64 + mb * 32 + fr_e;
+        const float* rv = p.rowvec ? p.rowvec + (size_t)((m < p.M ? m : 0) / p.rows_per_vec) * p.rowvec_ld : nullptr;
+        const int n = n0 + wn * WCOLS + nb * 32 + 8 * q + 4 * fh_e;
+        const bool nok = n < n_out;
+        float4 v = make_float4(acc[mb][nb][4 * q], acc[mb][nb][4 * q + 1], acc[mb][nb][4 * q + 2], acc[mb][nb][4 * q + 3]);
+        if (p.bias && nok) {
+            const float4 bv = *reinterpret_cast<const float4*>(p.bias + n);
+            v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+        }
+        if constexpr (GEGLU) {
+            float4 gt = make_float4(acc[mb][nb + NBX][4 * q], acc[mb][nb + NBX][4 * q + 1],
+                                    acc[mb][nb + NBX][4 * q + 2], acc[mb][nb + NBX][4 * q + 3]);
+            if (p.bias && nok) {
+                const float4 bg = *reinterpret_cast<const float4*>(p.bias + (p.N >> 1) + n);
+                gt.x += bg.x; gt.y += bg.y; gt.z += bg.z; gt.w += bg.w;
+            }
+            v.x *= gelu_erf_f(gt.x); v.y *= gelu_erf_f(gt.y); v.z *= gelu_erf_f(gt.z); v.w *= gelu_erf_f(gt.w);
+        }
+        if (p.flags & DC_GEMM_GELU) { v.x = gelu_erf_f(v.x); v.y = gelu_erf_f(v.y); v.z = gelu_erf_f(v.z); v.w = gelu_erf_f(v.w); }
+        if (rv && nok) {
+            const float4 r4 = *reinterpret_cast<const float4*>(rv + n);
+            v.x += r4.x; v.y += r4.y; v.z += r4.z; v.w += r4.w;
+        }
+        if (p.alpha != 1.0f) { v.x *= p.alpha; v.y *= p.alpha; v.z *= p.alpha; v.w *= p.alpha; }
+        return v;
+    };
+    if constexpr (EPI == 2) {
+        // fp32 outputs (VAE attention scores): direct accumulator-layout stores
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+            for (int nb = 0; nb < NBX; ++nb)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int m = m0 + wm * 64 + mb * 32 + fr_e;
+                    const int n = n0 + wn * WCOLS + nb * 32 + 8 * q + 4 * fh_e;
+                    const float4 v = finish(mb, nb, q);
+                    if (m < p.M && n < n_out) *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.C) + (size_t)m * p.ldc + n) = v;
+                }
+    } else {
+                const int rrow = lane_e >> 2, rc = lane_e & 3;     // read-back coordinates: row inside a 16-row pass, chunk
+        // 32-bit byte offsets from the (uniform) base pointers: one VGPR per (half, pass) row, the n-block is an
+        // instruction immediate (dispatch guarantees M * ld * 2 < 4 GiB, N % 8 == 0)
+        const int ncol = n0 + wn * WCOLS + rc * 8;
+        const char* const rbase = reinterpret_cast<const char*>(p.residual);
+        char* const cbase = reinterpret_cast<char*>(p.C);
+        auto row_off = [&](int mb, int t, int ld) __attribute__((always_inline)) -> unsigned {
+            int mr = m0 + wm * 64 + mb * 32 + t * 16 + rrow;
+            if (mr >= p.M) mr = p.M - 1;                    // clamped rows are loaded, never stored
+            return ((unsigned)mr * (unsigned)ld + (unsigned)(ncol + 8 <= n_out ? ncol : 0)) * 2u;
+        };
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb) {
+            unsigned co[2], ro[2];
+            bool rok[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                co[t] = row_off(mb, t, p.ldc);
+                ro[t] = row_off(mb, t, p.ldr);
+                rok[t] = m0 + wm * 64 + mb * 32 + t * 16 + rrow < p.M;
+            }
+#pragma unroll
+            for (int nb = 0; nb < NBX; ++nb) {
+                u32x4_t rr[2];
+                if constexpr (EPI == 1) {
+                    const int nbo = (ncol + nb * 32 + 8 <= n_out) ? nb * 64 : 0;      // stay inside the row
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) rr[t] = *reinterpret_cast<const u32x4_t*>(rbase + ro[t] + nbo);
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {   // row fr, 8-byte slot 2q+fh, XOR-swizzled by an even number per row pair
+                    const float4 v = finish(mb, nb, q);
+                    uint2 pk;
+                    pk.x = pack_bf2(v.x, v.y);
+                    pk.y = pack_bf2(v.z, v.w);
+                    *reinterpret_cast<uint2*>(ebuf + fr_e * 64 + (((2 * q + fh_e) ^ (((fr_e >> 1) & 3) << 1)) << 3)) = pk;
+                }
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const int r = t * 16 + rrow;
+                    u32x4_t d = *reinterpret_cast<const u32x4_t*>(ebuf + r * 64 + ((rc ^ ((r >> 1) & 3)) << 4));
+                    if (!rok[t] || ncol + nb * 32 + 8 > n_out) continue;
+                    if constexpr (EPI == 1) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            d[e] = pack_bf2(__uint_as_float(d[e] << 16) + __uint_as_float(rr[t][e] << 16),
+                                            __uint_as_float(d[e] & 0xffff0000u) + __uint_as_float(rr[t][e] & 0xffff0000u));
+                    }
+                    *reinterpret_cast<u32x4_t*>(cbase + co[t] + nb * 64) = d;
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+}
+
 // EPI: 0 bf16 | 1 bf16 + residual loaded in the epilogue | 2 fp32 | 3 bf16 + residual streamed through the ring.
 // EPI 3: the residual tile [256 x BN] follows the K tiles of its output tile through the LDS ring as BN/64 more
 // A-operand tiles and is added on the MFMA pipe (acc += R * I with an identity weight fragment built in registers):
@@ -704,109 +824,7 @@ __global__ __launch_bounds__(GNT) void gemm_persist_kernel(const DcGemmParams p)
             ++c_tile;
             const int tn = logical % tiles_n, tmi = logical / tiles_n;
             const int m0 = tmi * GBM, n0 = tn * BNOUT;
-            // lane coordinates re-derived behind an opaque move: otherwise every address below is loop-invariant, gets
-            // hoisted out of the K loop and is kept alive (spilled) across it
-            int lane_e = lane;
-            asm volatile("" : "+v"(lane_e));
-            const int fr_e = lane_e & 31, fh_e = lane_e >> 5;
-
-            // bias / GEGLU / GELU / per-row-group vector / alpha, in the accumulator layout
-            auto finish = [&](int mb, int nb, int q) __attribute__((always_inline)) -> float4 {
-                const int m = m0 + wm * 64 + mb * 32 + fr_e;
-                const float* rv = p.rowvec ? p.rowvec + (size_t)((m < p.M ? m : 0) / p.rows_per_vec) * p.rowvec_ld : nullptr;
-                const int n = n0 + wn * WCOLS + nb * 32 + 8 * q + 4 * fh_e;
-                const bool nok = n < n_out;
-                float4 v = make_float4(acc[mb][nb][4 * q], acc[mb][nb][4 * q + 1], acc[mb][nb][4 * q + 2], acc[mb][nb][4 * q + 3]);
-                if (p.bias && nok) {
-                    const float4 bv = *reinterpret_cast<const float4*>(p.bias + n);
-                    v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
-                }
-                if constexpr (GEGLU) {
-                    float4 gt = make_float4(acc[mb][nb + NBX][4 * q], acc[mb][nb + NBX][4 * q + 1],
-                                            acc[mb][nb + NBX][4 * q + 2], acc[mb][nb + NBX][4 * q + 3]);
-                    if (p.bias && nok) {
-                        const float4 bg = *reinterpret_cast<const float4*>(p.bias + (p.N >> 1) + n);
-                        gt.x += bg.x; gt.y += bg.y; gt.z += bg.z; gt.w += bg.w;
-                    }
-                    v.x *= gelu_erf_f(gt.x); v.y *= gelu_erf_f(gt.y); v.z *= gelu_erf_f(gt.z); v.w *= gelu_erf_f(gt.w);
-                }
-                if (p.flags & DC_GEMM_GELU) { v.x = gelu_erf_f(v.x); v.y = gelu_erf_f(v.y); v.z = gelu_erf_f(v.z); v.w = gelu_erf_f(v.w); }
-                if (rv && nok) {
-                    const float4 r4 = *reinterpret_cast<const float4*>(rv + n);
-                    v.x += r4.x; v.y += r4.y; v.z += r4.z; v.w += r4.w;
-                }
-                if (p.alpha != 1.0f) { v.x *= p.alpha; v.y *= p.alpha; v.z *= p.alpha; v.w *= p.alpha; }
-                return v;
-            };
-            if constexpr (EPI == 2) {
-                // fp32 outputs (VAE attention scores): direct accumulator-layout stores
-#pragma unroll
-                for (int mb = 0; mb < 2; ++mb)
-#pragma unroll
-                    for (int nb = 0; nb < NBX; ++nb)
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            const int m = m0 + wm * 64 + mb * 32 + fr_e;
-                            const int n = n0 + wn * WCOLS + nb * 32 + 8 * q + 4 * fh_e;
-                            const float4 v = finish(mb, nb, q);
-                            if (m < p.M && n < n_out) *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.C) + (size_t)m * p.ldc + n) = v;
-                        }
-            } else {
-                char* const ebuf = smem + GSTAGES * STAGE + wave * 2048;
-                const int rrow = lane_e >> 2, rc = lane_e & 3;     // read-back coordinates: row inside a 16-row pass, chunk
-                // 32-bit byte offsets from the (uniform) base pointers: one VGPR per (half, pass) row, the n-block is an
-                // instruction immediate (dispatch guarantees M * ld * 2 < 4 GiB, N % 8 == 0)
-                const int ncol = n0 + wn * WCOLS + rc * 8;
-                const char* const rbase = reinterpret_cast<const char*>(p.residual);
-                char* const cbase = reinterpret_cast<char*>(p.C);
-                auto row_off = [&](int mb, int t, int ld) __attribute__((always_inline)) -> unsigned {
-                    int mr = m0 + wm * 64 + mb * 32 + t * 16 + rrow;
-                    if (mr >= p.M) mr = p.M - 1;                    // clamped rows are loaded, never stored
-                    return ((unsigned)mr * (unsigned)ld + (unsigned)(ncol + 8 <= n_out ? ncol : 0)) * 2u;
-                };
-#pragma unroll
-                for (int mb = 0; mb < 2; ++mb) {
-                    unsigned co[2], ro[2];
-                    bool rok[2];
-#pragma unroll
-                    for (int t = 0; t < 2; ++t) {
-                        co[t] = row_off(mb, t, p.ldc);
-                        ro[t] = row_off(mb, t, p.ldr);
-                        rok[t] = m0 + wm * 64 + mb * 32 + t * 16 + rrow < p.M;
-                    }
-#pragma unroll
-                    for (int nb = 0; nb < NBX; ++nb) {
-                        u32x4_t rr[2];
-                        if constexpr (EPI == 1) {
-                            const int nbo = (ncol + nb * 32 + 8 <= n_out) ? nb * 64 : 0;      // stay inside the row
-#pragma unroll
-                            for (int t = 0; t < 2; ++t) rr[t] = *reinterpret_cast<const u32x4_t*>(rbase + ro[t] + nbo);
-                        }
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) {   // row fr, 8-byte slot 2q+fh, XOR-swizzled by an even number per row pair
-                            const float4 v = finish(mb, nb, q);
-                            uint2 pk;
-                            pk.x = pack_bf2(v.x, v.y);
-                            pk.y = pack_bf2(v.z, v.w);
-                            *reinterpret_cast<uint2*>(ebuf + fr_e * 64 + (((2 * q + fh_e) ^ (((fr_e >> 1) & 3) << 1)) << 3)) = pk;
-                        }
-#pragma unroll
-                        for (int t = 0; t < 2; ++t) {
-                            const int r = t * 16 + rrow;
-                            u32x4_t d = *reinterpret_cast<const u32x4_t*>(ebuf + r * 64 + ((rc ^ ((r >> 1) & 3)) << 4));
-                            if (!rok[t] || ncol + nb * 32 + 8 > n_out) continue;
-                            if constexpr (EPI == 1) {
-#pragma unroll
-                                for (int e = 0; e < 4; ++e)
-                                    d[e] = pack_bf2(__uint_as_float(d[e] << 16) + __uint_as_float(rr[t][e] << 16),
-                                                    __uint_as_float(d[e] & 0xffff0000u) + __uint_as_float(rr[t][e] & 0xffff0000u));
-                            }
-                            *reinterpret_cast<u32x4_t*>(cbase + co[t] + nb * 64) = d;
-                        }
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
-                }
-            }
+            persist_epilogue<BN, GEGLU, EPI>(acc, p, m0, n0, n_out, wm, wn, lane, smem + GSTAGES * STAGE + wave * 2048);
             zero_acc();
         }
     }
