@@ -1,0 +1,23 @@
+# Everything the round's numbers come from, on one box (run through gpurun):  bash tools/round_evidence.sh <tag>
+#   <tag>_bench1024.json          default bench line (20 steps; roofline table, measured cpu_baseline + parity check)
+#   <tag>_bench1024_guard.json    the same workload with DC_ARENA_GUARD=1 (scratch sentinels verified at full size)
+#   <tag>_bench512.json / 256     the other released configs (parity-test cases; builder-run numbers)
+#   tools/profile_step.sh         rocprofv3 kernel stats + PMC traffic table
+#   tools/pmc_one_gemm.sh         PMC counters of the level-0 linear [294912 x 320 x 320]
+TAG=${1:-r02}
+R=$GRAFT_REPO_ROOT
+O=$R/gpurun_out/$TAG
+mkdir -p $O
+cd $R
+python bench.py --steps 20 --warmup 2 > $O/${TAG}_bench1024.json 2> $O/bench1024.log || { tail -5 $O/bench1024.log; exit 1; }
+cp $O/${TAG}_bench1024.json $O/bench_full.json
+grep -E "timed|AE|cpu_baseline" $O/bench1024.log
+DC_ARENA_GUARD=1 python bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-trace > $O/${TAG}_bench1024_guard.json 2> $O/guard.log || { tail -5 $O/guard.log; exit 1; }
+grep -E "timed|guard" $O/guard.log
+python bench.py --res 512 --steps 20 --warmup 2 > $O/${TAG}_bench512.json 2> $O/bench512.log || { tail -5 $O/bench512.log; exit 1; }
+grep -E "timed|cpu_baseline: oracle" $O/bench512.log
+python bench.py --res 256 --steps 20 --warmup 2 > $O/${TAG}_bench256.json 2> $O/bench256.log || { tail -5 $O/bench256.log; exit 1; }
+grep -E "timed|cpu_baseline: oracle" $O/bench256.log
+bash tools/profile_step.sh $TAG > $O/profile.log 2>&1 || { tail -5 $O/profile.log; exit 1; }
+head -30 $O/${TAG}_traffic_by_kernel.md
+bash tools/pmc_one_gemm.sh lin320 lin 320 320 72 128 > $O/pmc.log 2>&1; python tools/pmc_summary.py $R/gpurun_out/pmc_lin320 > $O/${TAG}_pmc_lin320.txt 2>&1; tail -25 $O/${TAG}_pmc_lin320.txt
