@@ -42,15 +42,14 @@ __global__ void gn_partial_kernel(const bf16_t* __restrict__ x, int ldx, int C, 
     const bf16_t* base = x + (size_t)inst * rows_per_inst * ldx + v * 8;
     int r = r_begin + ro;
     const int n_t = r < r_end ? (r_end - r + rpp - 1) / rpp : 0;      // samples per channel of this thread
-    if (n_t > 0) {                                                      // shift = the thread's first sample of each channel
-        const uint4 raw = *reinterpret_cast<const uint4*>(base + (size_t)r * ldx);
-        unpack_bf8(raw, K);
-    }
+    bool have_k = false;        // shift = the thread's first sample of each channel, taken from the first batch of loads
+                                // (a separate load ahead of the loop costs a serial HBM round trip per chunk)
     // eight independent 16-byte loads in flight per lane (HBM latency, not issue rate, bounds this pass)
     for (; r + 7 * rpp < r_end; r += 8 * rpp) {
         uint4 raw[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) raw[u] = *reinterpret_cast<const uint4*>(base + (size_t)(r + u * rpp) * ldx);
+        if (!have_k) { unpack_bf8(raw[0], K); have_k = true; }
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             float f[8];
@@ -63,6 +62,7 @@ __global__ void gn_partial_kernel(const bf16_t* __restrict__ x, int ldx, int C, 
         const uint4 raw = *reinterpret_cast<const uint4*>(base + (size_t)r * ldx);
         float f[8];
         unpack_bf8(raw, f);
+        if (!have_k) { unpack_bf8(raw, K); have_k = true; }
 #pragma unroll
         for (int e = 0; e < 8; ++e) { const float d = f[e] - K[e]; s[e] += d; ss[e] += d * d; }
     }
@@ -88,9 +88,10 @@ __global__ void gn_partial_kernel(const bf16_t* __restrict__ x, int ldx, int C, 
             for (int c = 0; c < cpg; ++c) {
                 const float mb = sm_s[rr * C + g * cpg + c], qb = sm_q[rr * C + g * cpg + c];
                 const float nn = n + nb;
-                const float delta = mb - mean;
-                mean += delta * (nb / nn);
-                m2 += qb + delta * delta * (n * nb / nn);
+                const float w = nb * __builtin_amdgcn_rcpf(nn);   // 1-ulp reciprocal: a weight, not a sum (an IEEE divide
+                const float delta = mb - mean;                    // here is ~10 instructions on a 60-step serial chain)
+                mean += delta * w;
+                m2 += qb + delta * delta * (n * w);
                 n = nn;
             }
         }
@@ -112,9 +113,10 @@ __global__ __launch_bounds__(64) void gn_finalize_kernel(const float2* __restric
         if (rows > rows_per_chunk) rows = rows_per_chunk;
         const float nb = (float)rows * (float)cpg;
         const float nn = n + nb;
+        const float w = nb * __builtin_amdgcn_rcpf(nn);
         const float delta = p.x - mean;
-        mean += delta * (nb / nn);
-        m2 += p.y + delta * delta * (n * nb / nn);
+        mean += delta * w;
+        m2 += p.y + delta * delta * (n * w);
         n = nn;
     }
     // fixed shuffle tree of Chan merges (lanes without chunks carry n = 0)
@@ -123,9 +125,10 @@ __global__ __launch_bounds__(64) void gn_finalize_kernel(const float2* __restric
         const float nb = __shfl_xor(n, o, 64), mb = __shfl_xor(mean, o, 64), qb = __shfl_xor(m2, o, 64);
         const float nn = n + nb;
         if (nn > 0.f) {                                  // only lane 0's merge chain reaches the result; its order is fixed
+            const float w = nb * __builtin_amdgcn_rcpf(nn);
             const float delta = mb - mean;
-            mean += delta * (nb / nn);
-            m2 += qb + delta * delta * (n * nb / nn);
+            mean += delta * w;
+            m2 += qb + delta * delta * (n * w);
             n = nn;
         }
     }
