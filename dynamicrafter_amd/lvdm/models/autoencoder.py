@@ -224,6 +224,12 @@ class AutoencoderKL(nn.Module):
         mom = ops.gemm(h, P["quant"], self._buf("enc_mom", N * H * Wd, PADC, device=dev))
         return mom, (N, H, Wd)
 
+    def latent_hw(self, H, Wd):
+        """spatial size of the latent of an [.., H, W] image: one pad(0,1,0,1) + 3x3 stride-2 conv per level but the last"""
+        for _ in range(len(self.ddconfig["ch_mult"]) - 1):
+            H, Wd = (H + 1 - 3) // 2 + 1, (Wd + 1 - 3) // 2 + 1
+        return H, Wd
+
     def encode(self, x, **kwargs):
         if not x.is_cuda:
             raise RuntimeError("AutoencoderKL runs on the HIP path only (no CPU fallback)")
