@@ -32,11 +32,17 @@ constexpr int FA_STAGE = FA_KBYTES + FA_VBYTES;
 // QB = 32-row query blocks per wave. QB = 2 reads every K / V fragment from LDS once for two query blocks: at QB = 1
 // the kernel moves 16 KB of LDS reads per wave per 16 MFMAs, i.e. ~256 B/clk/CU at two workgroups per CU — the LDS
 // bandwidth itself — so doubling the MFMAs per fragment is what lifts the bound.
-template <int QB>
+// DUAL: two key/value sets with SEPARATE softmaxes over one query block - the text (k, v, Lk) and image (k2, v2, Lk2)
+// halves of DynamiCrafter's cross-attention, out = attn_text + acc_scale * attn_image (attention.py:128-142) - in one
+// pass over q and one store of o (as two launches the image pass re-read q and read-modify-wrote o).
+template <int QB, bool DUAL>
 __global__ __launch_bounds__(256, 2) void flash_attn_d64_kernel(
     const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v, bf16_t* __restrict__ o,
-    int ldq, int ldk, int ldv, int ldo, int heads, int Lq, int Lk, int64_t q_bstride, int64_t kv_bstride,
-    float c /* scale*log2(e) */, int accumulate, float acc_scale, int q_tiles) {
+    int ldq, int ldk, int ldv, int ldo, int heads, int Lq, int Lk_first, int64_t q_bstride, int64_t kv_bstride,
+    float c /* scale*log2(e) */, int accumulate, float acc_scale, int q_tiles, const bf16_t* __restrict__ k2,
+    const bf16_t* __restrict__ v2, int Lk2) {
+    static_assert(!DUAL || QB == 1, "the dual form keeps a second output accumulator: one query block per wave");
+    int Lk = Lk_first;
     __shared__ __attribute__((aligned(16))) char smem[2 * FA_STAGE];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fr = lane & 31, fh = lane >> 5;
@@ -99,7 +105,19 @@ __global__ __launch_bounds__(256, 2) void flash_attn_d64_kernel(
     };
 
     f32x16_t oacc[QB][2];
+    f32x16_t ofin[DUAL ? QB : 1][2];  // DUAL: normalised text result (+ scaled image result)
     float m_run[QB], l_run[QB];       // m_run: running row max in exp2 units (0 until the first tile sets it)
+    // per-lane byte offset of the transposed V read inside a 4-row block: lane i of a 16-lane group supplies
+    // row (i>>2), columns 4*(i&3).. of the 16-column block ((lane>>4)&1)
+    const int li = lane & 15;
+    const int tr_off = (li >> 2) * V_LD + (((lane >> 4) & 1) * 16 + (li & 3) * 4) * 2;
+#pragma unroll 1
+    for (int pass = 0; pass < (DUAL ? 2 : 1); ++pass) {
+    if (DUAL && pass == 1) {          // second key/value set; the LDS ring is free (the tile loop ends on a barrier)
+        kb = k2 + (size_t)b * kv_bstride * ldk + head * 64;
+        vb = v2 + (size_t)b * kv_bstride * ldv + head * 64;
+        Lk = Lk2;
+    }
 #pragma unroll
     for (int x = 0; x < QB; ++x) {
         m_run[x] = 0.f; l_run[x] = 0.f;
@@ -113,11 +131,6 @@ __global__ __launch_bounds__(256, 2) void flash_attn_d64_kernel(
     load_tile(0);
     store_tile(0);
     __syncthreads();
-
-    // per-lane byte offset of the transposed V read inside a 4-row block: lane i of a 16-lane group supplies
-    // row (i>>2), columns 4*(i&3).. of the 16-column block ((lane>>4)&1)
-    const int li = lane & 15;
-    const int tr_off = (li >> 2) * V_LD + (((lane >> 4) & 1) * 16 + (li & 3) * 4) * 2;
 
     for (int t = 0; t < nt; ++t) {
         const int buf = t & 1;
@@ -224,11 +237,30 @@ __global__ __launch_bounds__(256, 2) void flash_attn_d64_kernel(
         store_tile(buf ^ 1);
         __syncthreads();
     }
+    if constexpr (DUAL) {
+        // fold this pass into ofin: text result as is, image result times acc_scale
+#pragma unroll
+        for (int x = 0; x < QB; ++x) {
+            const float l_tot = l_run[x] + __shfl_xor(l_run[x], 32, 64);
+            const float wgt = (pass == 0 ? 1.0f : acc_scale) / l_tot;
+#pragma unroll
+            for (int d = 0; d < 2; ++d)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) ofin[x][d][r] = (pass == 0 ? 0.f : ofin[x][d][r]) + wgt * oacc[x][d][r];
+        }
+    }
+    }   // pass
 
 #pragma unroll
     for (int x = 0; x < QB; ++x) {
         const float l_tot = l_run[x] + __shfl_xor(l_run[x], 32, 64);
-        const float inv = 1.0f / l_tot;
+        const float inv = DUAL ? 1.0f : 1.0f / l_tot;
+        if constexpr (DUAL) {
+#pragma unroll
+            for (int d = 0; d < 2; ++d)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) oacc[x][d][r] = ofin[x][d][r];
+        }
         if (qrow[x] < Lq) {
             bf16_t* orow = ob + (size_t)qrow[x] * ldo;
 #pragma unroll
@@ -239,7 +271,7 @@ __global__ __launch_bounds__(256, 2) void flash_attn_d64_kernel(
                     float v0 = oacc[x][db][4 * qd + 0] * inv, v1 = oacc[x][db][4 * qd + 1] * inv;
                     float v2 = oacc[x][db][4 * qd + 2] * inv, v3 = oacc[x][db][4 * qd + 3] * inv;
                     uint2* dst = reinterpret_cast<uint2*>(orow + d);
-                    if (accumulate) {
+                    if (!DUAL && accumulate) {
                         const uint2 old = *dst;
                         v0 = __uint_as_float(old.x << 16) + acc_scale * v0;
                         v1 = __uint_as_float(old.x & 0xffff0000u) + acc_scale * v1;
@@ -365,11 +397,31 @@ extern "C" int dc_flash_attn_d64(const uint16_t* q, const uint16_t* k, const uin
     const long long nwg = (long long)q_tiles * heads * batch;
     if (nwg > 0x7fffffffLL) return DC_ERR_SHAPE;
     if (wide)
-        hipLaunchKernelGGL(flash_attn_d64_kernel<2>, dim3((unsigned)nwg), dim3(256), 0, stream, q, k, v, o, ldq, ldk, ldv,
-                           ldo, heads, Lq, Lk, q_bstride, kv_bstride, c, accumulate, acc_scale, q_tiles);
+        hipLaunchKernelGGL((flash_attn_d64_kernel<2, false>), dim3((unsigned)nwg), dim3(256), 0, stream, q, k, v, o, ldq, ldk, ldv,
+                           ldo, heads, Lq, Lk, q_bstride, kv_bstride, c, accumulate, acc_scale, q_tiles,
+                           (const bf16_t*)nullptr, (const bf16_t*)nullptr, 0);
     else
-        hipLaunchKernelGGL(flash_attn_d64_kernel<1>, dim3((unsigned)nwg), dim3(256), 0, stream, q, k, v, o, ldq, ldk, ldv,
-                           ldo, heads, Lq, Lk, q_bstride, kv_bstride, c, accumulate, acc_scale, q_tiles);
+        hipLaunchKernelGGL((flash_attn_d64_kernel<1, false>), dim3((unsigned)nwg), dim3(256), 0, stream, q, k, v, o, ldq, ldk, ldv,
+                           ldo, heads, Lq, Lk, q_bstride, kv_bstride, c, accumulate, acc_scale, q_tiles,
+                           (const bf16_t*)nullptr, (const bf16_t*)nullptr, 0);
+    DC_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int dc_cross_attn_dual_d64(const uint16_t* q, const uint16_t* k, const uint16_t* v, const uint16_t* k2,
+                                      const uint16_t* v2, uint16_t* o, int ldq, int ldkv, int ldo, int batch, int heads,
+                                      int Lq, int Lk, int Lk2, int64_t q_bstride, int64_t kv_bstride, float scale,
+                                      float scale2, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!q || !k || !v || !k2 || !v2 || !o) return DC_ERR_ARG;
+    if (batch <= 0 || heads <= 0 || Lq <= 0 || Lk <= 0 || Lk2 <= 0) return DC_ERR_SHAPE;
+    if (ldq % 8 || ldkv % 8 || ldo % 4) return DC_ERR_SHAPE;
+    const float c = scale * 1.4426950408889634f;
+    const int q_tiles = (Lq + FA_BQ - 1) / FA_BQ;
+    const long long nwg = (long long)q_tiles * heads * batch;
+    if (nwg > 0x7fffffffLL) return DC_ERR_SHAPE;
+    hipLaunchKernelGGL((flash_attn_d64_kernel<1, true>), dim3((unsigned)nwg), dim3(256), 0, stream, q, k, v, o, ldq, ldkv, ldkv,
+                       ldo, heads, Lq, Lk, q_bstride, kv_bstride, c, 0, scale2, q_tiles, k2, v2, Lk2);
     DC_CHECK_LAUNCH();
     return 0;
 }

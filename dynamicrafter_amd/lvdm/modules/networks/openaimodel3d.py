@@ -448,11 +448,13 @@ class UNetModel(nn.Module):
             kv = self._context_kv(B_, g["ctx"], "kvctx")       # rows [F * Lc, 4C], Lc = n_text + L_img
         att = A.get("att", M, Cc, device=dev)
         Lc, nt = g["Lc"], g["n_text"]
-        ops.flash_attn(q, kv[:, :Cc], kv[:, Cc:2 * Cc], att, batch=g["F"], heads=heads, Lq=g["HW"], Lk=nt, scale=0.125,
-                       kv_bstride=Lc)
         if self.image_cross_attention and Lc > nt:
-            ops.flash_attn(q, kv[nt:, 2 * Cc:3 * Cc], kv[nt:, 3 * Cc:], att, batch=g["F"], heads=heads, Lq=g["HW"],
-                           Lk=Lc - nt, scale=0.125, kv_bstride=Lc, accumulate=True, acc_scale=B_["ip_scale"])
+            # text keys and image keys, two softmaxes, one launch: out = attn_text + ip_scale * attn_image
+            ops.cross_attn_dual(q, kv[:, :Cc], kv[:, Cc:2 * Cc], kv[nt:, 2 * Cc:3 * Cc], kv[nt:, 3 * Cc:], att, batch=g["F"],
+                                heads=heads, Lq=g["HW"], Lk=nt, Lk2=Lc - nt, scale=0.125, scale2=B_["ip_scale"], kv_bstride=Lc)
+        else:
+            ops.flash_attn(q, kv[:, :Cc], kv[:, Cc:2 * Cc], att, batch=g["F"], heads=heads, Lq=g["HW"], Lk=nt, scale=0.125,
+                           kv_bstride=Lc)
         h = ops.gemm(att, B_["out2"], h, residual=h)
         h = self._ff(B_, h)
         return ops.gemm(h, W["proj_out"], out if out is not None else A.get(out_tag, M, Cc, device=dev), residual=x)

@@ -361,6 +361,22 @@ def flash_attn(q, k, v, o, *, batch, heads, Lq, Lk, scale, accumulate=False, acc
     return o
 
 
+def cross_attn_dual(q, k, v, k2, v2, o, *, batch, heads, Lq, Lk, Lk2, scale, scale2, kv_bstride):
+    """o = attn(q; k, v) + scale2 * attn(q; k2, v2): text + image cross-attention of one query tensor in one launch.
+    k/v/k2/v2 are column views of one projection buffer (same row stride), kv_bstride rows per batch item."""
+    for t, n in ((q, "q"), (k, "k"), (v, "v"), (k2, "k2"), (v2, "v2"), (o, "o")):
+        _rows(t, n)
+    if len({k.stride(0), v.stride(0), k2.stride(0), v2.stride(0)}) != 1:
+        raise ValueError("cross_attn_dual: k, v, k2, v2 must share one row stride")
+    _need_rows(q, batch * Lq, heads * 64, "q"); _need_rows(o, batch * Lq, heads * 64, "o")
+    _need_rows(k, (batch - 1) * kv_bstride + Lk, heads * 64, "k"); _need_rows(v, (batch - 1) * kv_bstride + Lk, heads * 64, "v")
+    _need_rows(k2, (batch - 1) * kv_bstride + Lk2, heads * 64, "k2"); _need_rows(v2, (batch - 1) * kv_bstride + Lk2, heads * 64, "v2")
+    _launch("flash_attn_d64(cross)", 4.0 * batch * heads * Lq * (Lk + Lk2) * 64, 2.0 * batch * heads * 64 * (2 * Lq + 2 * (Lk + Lk2)),
+            _hip.lib().dc_cross_attn_dual_d64, _ptr(q), _ptr(k), _ptr(v), _ptr(k2), _ptr(v2), _ptr(o), q.stride(0), k.stride(0),
+            o.stride(0), batch, heads, Lq, Lk, Lk2, Lq, kv_bstride, scale, scale2, stream_ptr())
+    return o
+
+
 def temporal_attn(qkv, o, *, B, T, HW, heads, scale):
     _rows(qkv, "qkv"); _rows(o, "o")
     _need_rows(qkv, B * T * HW, 3 * heads * 64, "qkv"); _need_rows(o, B * T * HW, heads * 64, "o")

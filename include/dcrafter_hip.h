@@ -174,6 +174,14 @@ int dc_ddim_step(const DcDdimParams* p, const float* e_cond, const float* e_unco
                  const float* x, const float* noise, float* x_prev, float* pred_x0, int B, int C, int THW,
                  float* workspace, void* stream);
 
+/* DynamiCrafter's dual cross-attention in one launch: o = softmax(s q k^T) v + scale2 * softmax(s q k2^T) v2 with two
+ * independent softmaxes (text keys Lk, image keys Lk2) over the same queries; head_dim 64. q/o rows as in
+ * dc_flash_attn_d64; k, v, k2, v2 rows share the stride ldkv and the batch stride kv_bstride (views into one fused
+ * projection buffer). replaces CrossAttention.forward lvdm/modules/attention.py:128-142 (image_cross_attention) */
+int dc_cross_attn_dual_d64(const uint16_t* q, const uint16_t* k, const uint16_t* v, const uint16_t* k2, const uint16_t* v2,
+                           uint16_t* o, int ldq, int ldkv, int ldo, int batch, int heads, int Lq, int Lk, int Lk2,
+                           int64_t q_bstride, int64_t kv_bstride, float scale, float scale2, void* stream);
+
 /* ---- conditioning encoders (once per clip) ---------------------------------------------------- */
 
 /* Multi-head attention for any (even) head width d <= 256 and Lk <= 1024, optional causal mask (key j visible to query

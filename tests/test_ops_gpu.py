@@ -618,3 +618,26 @@ def test_clip_preprocess_patchify_embed_vs_oracle(ops):
     ops.embed_tokens(tok.to(DEV), table.to(DEV), pos.to(DEV), out)
     ref = (table.float()[tok] + pos.float()).reshape(21, 64).to(torch.bfloat16)
     assert torch.equal(out.cpu(), ref)
+
+
+@pytest.mark.parametrize("B,heads,Lq,nt,ni,s2", [(3, 5, 300, 77, 16, 1.0), (2, 2, 70, 77, 16, 1.7), (1, 20, 144, 5, 3, 0.4)])
+def test_cross_attn_dual_vs_torch(ops, B, heads, Lq, nt, ni, s2):
+    """Text + image cross-attention with separate softmaxes in one launch (attention.py:128-142) vs fp32 torch, and vs the
+    two-launch form (text pass, then accumulate the image pass)."""
+    g = torch.Generator().manual_seed(9)
+    Cc, Lc = heads * 64, nt + ni
+    q = torch.randn(B * Lq, Cc, generator=g).to(torch.bfloat16).to(DEV)
+    kv = torch.randn(B * Lc, 4 * Cc, generator=g).to(torch.bfloat16).to(DEV)
+    o = torch.empty(B * Lq, Cc, dtype=torch.bfloat16, device=DEV)
+    ops.cross_attn_dual(q, kv[:, :Cc], kv[:, Cc:2 * Cc], kv[nt:, 2 * Cc:3 * Cc], kv[nt:, 3 * Cc:], o, batch=B, heads=heads,
+                        Lq=Lq, Lk=nt, Lk2=ni, scale=0.125, scale2=s2, kv_bstride=Lc)
+    qf = q.float().cpu().reshape(B, Lq, Cc)
+    kvf = kv.float().cpu().reshape(B, Lc, 4 * Cc)
+    ref = (_attn_ref(qf, kvf[:, :nt, :Cc], kvf[:, :nt, Cc:2 * Cc], heads, 0.125)
+           + s2 * _attn_ref(qf, kvf[:, nt:, 2 * Cc:3 * Cc], kvf[:, nt:, 3 * Cc:], heads, 0.125))
+    assert rel_l2(o, ref.reshape(B * Lq, Cc)) < 6e-3
+    o2 = torch.empty_like(o)
+    ops.flash_attn(q, kv[:, :Cc], kv[:, Cc:2 * Cc], o2, batch=B, heads=heads, Lq=Lq, Lk=nt, scale=0.125, kv_bstride=Lc)
+    ops.flash_attn(q, kv[nt:, 2 * Cc:3 * Cc], kv[nt:, 3 * Cc:], o2, batch=B, heads=heads, Lq=Lq, Lk=ni, scale=0.125,
+                   kv_bstride=Lc, accumulate=True, acc_scale=s2)
+    assert rel_l2(o, o2) < 6e-3
