@@ -53,7 +53,9 @@ typedef struct DcGemmParams {
     long long workspace_bytes;
 } DcGemmParams;
 
-/* Name of the kernel family the last dc_gemm_conv call of this host thread dispatched to (profiling label). */
+/* Name of the kernel family the last dc_gemm_conv call of this host thread dispatched to. A thread-local DIAGNOSTIC label
+ * for profilers (bench.py's per-kernel table): it carries no state any compute entry reads - the compute ABI stays
+ * stateless. */
 const char* dc_gemm_last_variant(void);
 
 /* Recommended size of DcGemmParams.workspace (one buffer per stream; contents are scratch, no initialisation). */
