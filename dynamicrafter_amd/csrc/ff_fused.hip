@@ -1,0 +1,349 @@
+// Fused GEGLU FeedForward for dim = 320 (the UNet's level-0 transformers):
+//
+//   out[M, 320] = ( (X W1v^T + b1v) * gelu(X W1g^T + b1g) ) W2^T + b2 + residual        reference: FeedForward /
+//   GEGLU, lvdm/modules/attention.py:415-442, called from BasicTransformerBlock._forward :246
+//
+// without the [M, 1280] intermediate ever leaving the CU. As two GEMMs that intermediate is written and read back once
+// per FeedForward: 2 x 755 MB per level-0 block at the 1024 config, 28 GB per denoising step, and the first GEMM's
+// 256 x 256 tiles pay a GEGLU epilogue every five K tiles (K = 320).
+//
+// Structure: ONE wave per SIMD (4 waves per workgroup, 1 workgroup per CU, up to 512 registers per lane). A workgroup
+// owns 128 rows; wave w owns rows [32 w, 32 w + 32) of it for the whole FeedForward:
+//   * X fragments of its rows stay in registers (20 x bf16x8 = 80 VGPRs), loaded once per tile straight from HBM;
+//   * the 1280 intermediate channels are walked in 40 chunks of 32. Per chunk the workgroup streams the 64 rows of W1
+//     (32 value + 32 gate rows x 320) and the 32 columns of W2 (320 x 32) through LDS by LDS-DMA (two-deep rings, 60 KB
+//     per chunk), one barrier per chunk;
+//   * phase 1: Pv, Pg = X W1v^T, X W1g^T   (2 accumulators, 40 MFMAs 32x32x16); GEGLU on the accumulators;
+//   * phase 2: out += P W2c^T              (10 accumulators, 20 MFMAs) - P never leaves registers: with the swapped
+//     operand order a lane holds, for ITS row, 16 of the chunk's 32 channels, which is exactly a B-operand fragment
+//     pair once the k order is agreed on; the host packs W2 with that order inside every 32-channel chunk
+//     (position 16 s + 8 h + e  <->  channel 8 (2 s + e / 4) + 4 h + e % 4);
+//   * epilogue: + b2, bf16, + residual, row-major stores through a wave-private LDS patch.
+// Every weight fragment read from LDS feeds one MFMA (1 KB per MFMA: the LDS peak at the full MFMA rate) and a
+// workgroup streams W1 + W2 (2.4 MB) per 128 rows (the ~32 B/clk L2 -> LDS path at the full MFMA rate): both bounds sit
+// at ~100 %, the kernel is designed to run at about half of that.
+#include "dc_common.h"
+#include "dcrafter_hip.h"
+#include <stdint.h>
+#include <type_traits>
+
+namespace {
+
+constexpr int FD = 320;            // model width (K of ff1, N of ff2)
+constexpr int FM = 4 * FD;         // intermediate width 1280
+constexpr int FCH = 32;            // intermediate channels per chunk
+constexpr int FNCH = FM / FCH;     // 40 chunks
+constexpr int FBM = 128;           // rows per workgroup tile
+constexpr int W1_STAGE = 64 * FD * 2;          // 40 KB: 5 K tiles of [64 rows][128 B]
+constexpr int W2_STAGE = FD * FCH * 2;         // 20 KB: [320 rows][64 B]
+constexpr int FF_LDS = 2 * W1_STAGE + 2 * W2_STAGE + 4 * 2048 + 2 * FM * 4;    // rings + epilogue patches + b1 (fp32)
+
+typedef __attribute__((address_space(3))) char lds_char_t;
+__device__ __attribute__((aligned(16))) uint32_t g_zero_ff[8];
+
+__device__ __forceinline__ int off128(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
+__device__ __forceinline__ int off64(int row, int chunk) { return row * 64 + ((chunk ^ ((row >> 2) & 3)) << 4); }
+
+__device__ __forceinline__ void glds16f(const void* gsrc, unsigned lds_dst_uniform) {
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %2\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, off\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(gsrc), "s"(lds_dst_uniform)
+        : "memory");
+}
+
+struct FfParams {
+    const bf16_t* X; int ldx;
+    const bf16_t* W1;            // [>= 2560][320]: rows 0..1279 value, 1280..2559 gate (torch ff.net.0.proj.weight order)
+    const float* b1;             // [2560]
+    const bf16_t* W2p;           // [>= 320][1280], k permuted inside every 32-chunk
+    const float* b2;             // [320]
+    const bf16_t* R; int ldr;    // residual or nullptr
+    bf16_t* O; int ldo;
+    int M;
+};
+
+__global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1)))
+void ff_geglu_fused320_kernel(const FfParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fr = lane & 31, fh = lane >> 5;
+    const unsigned lds_base = (unsigned)(unsigned long)((lds_char_t*)smem);
+    char* const w1s = smem;                              // 2 x W1_STAGE
+    char* const w2s = smem + 2 * W1_STAGE;               // 2 x W2_STAGE
+    char* const ebuf = smem + 2 * W1_STAGE + 2 * W2_STAGE + wave * 2048;
+
+    const int tiles = (p.M + FBM - 1) / FBM;
+    // ff1 bias (2560 floats) staged once: a global load per chunk sat ~500 cycles in front of every GEGLU
+    float* const b1s = reinterpret_cast<float*>(smem + 2 * W1_STAGE + 2 * W2_STAGE + 4 * 2048);
+    for (int i = tid; i < 2 * FM; i += 256) b1s[i] = p.b1[i];
+    __syncthreads();
+
+    // LDS-DMA of chunk j: W1 rows (10 instructions of 8 rows x 128 B per wave) and W2 columns (5 instructions of 16 rows x
+    // 64 B per wave), each into stage (j & 1) of its own two-deep ring. Addressing = 64-bit SCALAR base (SALU, free next
+    // to the vector pipes) + one of three per-lane 32-bit offsets computed once per kernel; m0 (the LDS destination)
+    // advances by 1 KB per instruction inside one asm block. (Per-lane 64-bit pointer arithmetic and an m0 save /
+    // restore around every instruction cost 1100 cycles per chunk: 15 % of the kernel.)
+    const unsigned voff1[2] = {
+        (unsigned)((lane >> 3) * (FD * 2) + (((lane & 7) ^ ((0 * 4 + (lane >> 4)) & 7)) << 4)),     // 8-row group index even
+        (unsigned)((lane >> 3) * (FD * 2) + (((lane & 7) ^ ((1 * 4 + (lane >> 4)) & 7)) << 4))};    // odd
+    const unsigned voff2 = (unsigned)((lane >> 2) * (FM * 2) + (((lane & 3) ^ ((lane >> 4) & 3)) << 4));
+    auto issue_w1 = [&](int j) __attribute__((always_inline)) {
+        const unsigned dst0 = lds_base + (j & 1) * W1_STAGE + wave * 10 * 1024;
+        uint64_t sb[10];
+#pragma unroll
+        for (int i = 0; i < 10; ++i) {
+            const int u = wave * 10 + i;                 // (K tile t, 8-row group g): LDS offset u * 1024
+            const int t = u >> 3, g = u & 7;             // rows g*8 .. +7 of the 64-row chunk: g < 4 value, else gate
+            const int wrow = g < 4 ? j * FCH + g * 8 : FM + j * FCH + (g - 4) * 8;
+            sb[i] = (uint64_t)(uintptr_t)p.W1 + (uint64_t)wrow * (FD * 2) + t * 128;
+        }
+        unsigned keep;
+        asm volatile(
+            "s_mov_b32 %[keep], m0\n\t"
+            "s_mov_b32 m0, %[d0]\n\t"
+            "s_nop 0\n\t"
+            "global_load_lds_dwordx4 %[va], %[s0]\n\t"
+            "s_add_u32 m0, m0, 0x400\n\t"
+            "s_nop 0\n\t"
+            "global_load_lds_dwordx4 %[vb], %[s1]\n\t"
+            "s_add_u32 m0, m0, 0x400\n\t"
+            "s_nop 0\n\t"
+            "global_load_lds_dwordx4 %[va], %[s2]\n\t"
+            "s_add_u32 m0, m0, 0x400\n\t"
+            "s_nop 0\n\t"
+            "global_load_lds_dwordx4 %[vb], %[s3]\n\t"
+            "s_add_u32 m0, m0, 0x400\n\t"
+            "s_nop 0\n\t"
+            "global_load_lds_dwordx4 %[va], %[s4]\n\t"
+            "s_add_u32 m0, m0, 0x400\n\t"
+            "s_nop 0\n\t"
+            "global_load_lds_dwordx4 %[vb], %[s5]\n\t"
+            "s_add_u32 m0, m0, 0x400\n\t"
+            "s_nop 0\n\t"
+            "global_load_lds_dwordx4 %[va], %[s6]\n\t"
+            "s_add_u32 m0, m0, 0x400\n\t"
+            "s_nop 0\n\t"
+            "global_load_lds_dwordx4 %[vb], %[s7]\n\t"
+            "s_add_u32 m0, m0, 0x400\n\t"
+            "s_nop 0\n\t"
+            "global_load_lds_dwordx4 %[va], %[s8]\n\t"
+            "s_add_u32 m0, m0, 0x400\n\t"
+            "s_nop 0\n\t"
+            "global_load_lds_dwordx4 %[vb], %[s9]\n\t"
+            "s_mov_b32 m0, %[keep]"
+            : [keep] "=&s"(keep)
+            : [d0] "s"(dst0), [va] "v"(voff1[0]), [vb] "v"(voff1[1]), [s0] "s"(sb[0]), [s1] "s"(sb[1]), [s2] "s"(sb[2]),
+              [s3] "s"(sb[3]), [s4] "s"(sb[4]), [s5] "s"(sb[5]), [s6] "s"(sb[6]), [s7] "s"(sb[7]), [s8] "s"(sb[8]), [s9] "s"(sb[9])
+            : "memory", "scc");
+    };
+    auto issue_w2 = [&](int j) __attribute__((always_inline)) {
+        const unsigned dst0 = lds_base + 2 * W1_STAGE + (j & 1) * W2_STAGE + wave * 5 * 1024;
+        uint64_t sb[5];
+#pragma unroll
+        for (int i = 0; i < 5; ++i)                       // 16-row group wave*5 + i of the 320 output channels
+            sb[i] = (uint64_t)(uintptr_t)p.W2p + (uint64_t)((wave * 5 + i) * 16) * (FM * 2) + j * (FCH * 2);
+        unsigned keep;
+        asm volatile(
+            "s_mov_b32 %[keep], m0\n\t"
+            "s_mov_b32 m0, %[d0]\n\t"
+            "s_nop 0\n\t"
+            "global_load_lds_dwordx4 %[va], %[s0]\n\t"
+            "s_add_u32 m0, m0, 0x400\n\t"
+            "s_nop 0\n\t"
+            "global_load_lds_dwordx4 %[va], %[s1]\n\t"
+            "s_add_u32 m0, m0, 0x400\n\t"
+            "s_nop 0\n\t"
+            "global_load_lds_dwordx4 %[va], %[s2]\n\t"
+            "s_add_u32 m0, m0, 0x400\n\t"
+            "s_nop 0\n\t"
+            "global_load_lds_dwordx4 %[va], %[s3]\n\t"
+            "s_add_u32 m0, m0, 0x400\n\t"
+            "s_nop 0\n\t"
+            "global_load_lds_dwordx4 %[va], %[s4]\n\t"
+            "s_mov_b32 m0, %[keep]"
+            : [keep] "=&s"(keep)
+            : [d0] "s"(dst0), [va] "v"(voff2), [s0] "s"(sb[0]), [s1] "s"(sb[1]), [s2] "s"(sb[2]), [s3] "s"(sb[3]), [s4] "s"(sb[4])
+            : "memory", "scc");
+    };
+
+    for (int tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+        const int m0 = tile * FBM + wave * 32;
+        // ---- X fragments of this wave's 32 rows (B operand: lane (row fr, half fh) holds k = 16 kk + 8 fh .. + 7)
+        bf16x8_t xf[FD / 16];
+        {
+            int mr = m0 + fr;
+            if (mr >= p.M) mr = p.M - 1;
+            const bf16_t* xr = p.X + (size_t)mr * p.ldx + fh * 8;
+#pragma unroll
+            for (int kk = 0; kk < FD / 16; ++kk) xf[kk] = *reinterpret_cast<const bf16x8_t*>(xr + kk * 16);
+        }
+        f32x16_t acc[FD / 32];
+#pragma unroll
+        for (int nb = 0; nb < FD / 32; ++nb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[nb][r] = 0.f;
+
+        constexpr int PD = 4;           // LDS fragments are read PD steps ahead of the MFMA that consumes them (one wave per
+                                        // SIMD: nothing else hides the LDS latency)
+        // phase 1 of chunk c: value / gate pre-activations of its 32 channels for this wave's 32 rows
+        auto phase1 = [&](int c, f32x16_t& av, f32x16_t& ag) __attribute__((always_inline)) {
+            const char* s1 = w1s + (c & 1) * W1_STAGE;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { av[r] = 0.f; ag[r] = 0.f; }
+            bf16x8_t wv[PD], wg[PD];
+            auto rd1 = [&](int kk, int slot) __attribute__((always_inline)) {
+                const char* kt = s1 + (kk >> 2) * 8192;
+                wv[slot] = *reinterpret_cast<const bf16x8_t*>(kt + off128(fr, (kk & 3) * 2 + fh));
+                wg[slot] = *reinterpret_cast<const bf16x8_t*>(kt + off128(32 + fr, (kk & 3) * 2 + fh));
+            };
+#pragma unroll
+            for (int kk = 0; kk < PD; ++kk) rd1(kk, kk);
+#pragma unroll
+            for (int kk = 0; kk < FD / 16; ++kk) {
+                const bf16x8_t cv = wv[kk % PD], cg = wg[kk % PD];
+                if (kk + PD < FD / 16) rd1(kk + PD, kk % PD);
+                av = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cv, xf[kk], av, 0, 0, 0);
+                ag = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cg, xf[kk], ag, 0, 0, 0);
+            }
+        };
+        // GEGLU of chunk c on its accumulators -> the two B-operand fragments of phase 2 (lane (row fr, fh) holds
+        // channels 8 q + 4 fh + i of the chunk)
+        auto geglu = [&](int c, const f32x16_t& av, const f32x16_t& ag, bf16x8_t (&pf)[2]) __attribute__((always_inline)) {
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                u32x4_t pw;
+#pragma unroll
+                for (int h2 = 0; h2 < 2; ++h2) {
+                    const int q = 2 * s + h2;
+                    const int n = c * FCH + 8 * q + 4 * fh;
+                    const float4 bv = *reinterpret_cast<const float4*>(b1s + n);
+                    const float4 bg = *reinterpret_cast<const float4*>(b1s + FM + n);
+                    const float v0 = (av[4 * q + 0] + bv.x) * gelu_erf_f(ag[4 * q + 0] + bg.x);
+                    const float v1 = (av[4 * q + 1] + bv.y) * gelu_erf_f(ag[4 * q + 1] + bg.y);
+                    const float v2 = (av[4 * q + 2] + bv.z) * gelu_erf_f(ag[4 * q + 2] + bg.z);
+                    const float v3 = (av[4 * q + 3] + bv.w) * gelu_erf_f(ag[4 * q + 3] + bg.w);
+                    pw[2 * h2] = pack_bf2(v0, v1);
+                    pw[2 * h2 + 1] = pack_bf2(v2, v3);
+                }
+                pf[s] = __builtin_bit_cast(bf16x8_t, pw);
+            }
+        };
+        // phase 2 of chunk c: out[row][ch] += P W2c^T (W2 packed in the matching k order)
+        auto phase2 = [&](int c, const bf16x8_t (&pf)[2]) __attribute__((always_inline)) {
+            const char* s2 = w2s + (c & 1) * W2_STAGE;
+            bf16x8_t w2r[PD];
+            auto rd2 = [&](int idx, int slot) __attribute__((always_inline)) {      // idx = s * 10 + nb
+                const int s = idx / (FD / 32), nb = idx % (FD / 32);
+                w2r[slot] = *reinterpret_cast<const bf16x8_t*>(s2 + off64(nb * 32 + fr, s * 2 + fh));
+            };
+#pragma unroll
+            for (int i = 0; i < PD; ++i) rd2(i, i);
+#pragma unroll
+            for (int idx = 0; idx < 2 * (FD / 32); ++idx) {
+                const int s = idx / (FD / 32), nb = idx % (FD / 32);
+                const bf16x8_t cw = w2r[idx % PD];
+                if (idx + PD < 2 * (FD / 32)) rd2(idx + PD, idx % PD);
+                acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cw, pf[s], acc[nb], 0, 0, 0);
+            }
+        };
+        // Software pipeline over the 40 chunks: iteration j runs phase 1 of chunk j+1 (MFMA pipe) in the same
+        // instruction stream as the GEGLU arithmetic of chunk j (vector ALU) - independent data, so the MFMAs run
+        // under the erf/exp/convert work - then phase 2 of chunk j. LDS-DMA: W1(j+2) and W2(j+1) are issued at the top
+        // of iteration j (their stages held W1(j) / W2(j-1), both consumed in iteration j-1) and waited for, with
+        // vmcnt(0) + one barrier, at the top of iteration j+1.
+        __builtin_amdgcn_s_barrier();                    // every wave is done with the previous tile's LDS stages
+        issue_w1(0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // W1(0) (and the X fragments)
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        issue_w1(1);
+        issue_w2(0);
+        f32x16_t a0v, a0g, a1v, a1g;
+        phase1(0, a0v, a0g);
+        auto body = [&](int j, f32x16_t& cv, f32x16_t& cg, f32x16_t& nv, f32x16_t& ng) __attribute__((always_inline)) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // W1(j+1), W2(j)
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            if (j + 2 < FNCH) issue_w1(j + 2);
+            if (j + 1 < FNCH) issue_w2(j + 1);
+            bf16x8_t pf[2];
+            // (Putting phase 1 and GEGLU into ONE basic block - unconditional phase 1, with or without a
+            // sched_group_barrier pattern of 1 MFMA : 1 LDS read : 11 VALU - made hipcc spill 55-64 registers; behind this
+            // branch it fits the 512 and still lets a third of the phase-1 MFMAs issue inside the GEGLU stream.)
+            if (j + 1 < FNCH) phase1(j + 1, nv, ng);
+            geglu(j, cv, cg, pf);
+            phase2(j, pf);
+        };
+        for (int j = 0; j < FNCH; j += 2) {
+            body(j, a0v, a0g, a1v, a1g);
+            body(j + 1, a1v, a1g, a0v, a0g);
+        }
+        // ---- epilogue: + b2, bf16, + residual; row-major through the wave-private patch (32 rows x 64 B per block)
+        {
+            int lane_e = lane;
+            asm volatile("" : "+v"(lane_e));
+            const int fr_e = lane_e & 31, fh_e = lane_e >> 5;
+            const int rrow = lane_e >> 2, rc = lane_e & 3;
+#pragma unroll
+            for (int nb = 0; nb < FD / 32; ++nb) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int n = nb * 32 + 8 * q + 4 * fh_e;
+                    const float4 bv = *reinterpret_cast<const float4*>(p.b2 + n);
+                    uint2 pk;
+                    pk.x = pack_bf2(acc[nb][4 * q] + bv.x, acc[nb][4 * q + 1] + bv.y);
+                    pk.y = pack_bf2(acc[nb][4 * q + 2] + bv.z, acc[nb][4 * q + 3] + bv.w);
+                    *reinterpret_cast<uint2*>(ebuf + fr_e * 64 + (((2 * q + fh_e) ^ (((fr_e >> 1) & 3) << 1)) << 3)) = pk;
+                }
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const int r = t * 16 + rrow;
+                    u32x4_t d = *reinterpret_cast<const u32x4_t*>(ebuf + r * 64 + ((rc ^ ((r >> 1) & 3)) << 4));
+                    const int m = m0 + r;
+                    if (m >= p.M) continue;
+                    const int n = nb * 32 + rc * 8;
+                    if (p.R) {
+                        const u32x4_t rr = *reinterpret_cast<const u32x4_t*>(p.R + (size_t)m * p.ldr + n);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            d[e] = pack_bf2(__uint_as_float(d[e] << 16) + __uint_as_float(rr[e] << 16),
+                                            __uint_as_float(d[e] & 0xffff0000u) + __uint_as_float(rr[e] & 0xffff0000u));
+                    }
+                    *reinterpret_cast<u32x4_t*>(p.O + (size_t)m * p.ldo + n) = d;
+                }
+            }
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int dc_ff_geglu_fused320(const uint16_t* x, int ldx, const uint16_t* w1, const float* b1, const uint16_t* w2p,
+                                    const float* b2, const uint16_t* residual, int ldr, uint16_t* out, int ldo, int M,
+                                    void* stream_) {
+    if (!x || !w1 || !b1 || !w2p || !b2 || !out) return DC_ERR_ARG;
+    if (M < 1 || ldx % 8 || ldo % 8 || (residual && ldr % 8)) return DC_ERR_SHAPE;
+    if (((uintptr_t)x | (uintptr_t)out | (uintptr_t)w1 | (uintptr_t)w2p | (uintptr_t)(residual ? residual : out)) % 16) return DC_ERR_SHAPE;
+    static bool configured = false;
+    if (!configured) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ff_geglu_fused320_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, FF_LDS);
+        if (e != hipSuccess) return (int)e;
+        configured = true;
+    }
+    FfParams p;
+    p.X = x; p.ldx = ldx; p.W1 = w1; p.b1 = b1; p.W2p = w2p; p.b2 = b2; p.R = residual; p.ldr = ldr; p.O = out; p.ldo = ldo;
+    p.M = M;
+    const int tiles = (M + FBM - 1) / FBM;
+    hipLaunchKernelGGL(ff_geglu_fused320_kernel, dim3(tiles < 256 ? tiles : 256), dim3(256), FF_LDS, (hipStream_t)stream_, p);
+    DC_CHECK_LAUNCH();
+    return 0;
+}

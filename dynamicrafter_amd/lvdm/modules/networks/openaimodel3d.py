@@ -22,7 +22,10 @@ from .... import ops
 from ....ops import PackedWeight
 from ....param_tree import attach_params
 
+import os
+
 _BF16 = torch.bfloat16
+_FF_FUSED = os.environ.get("DC_FF_FUSED", "1") != "0"
 C_IN_PAD = 64   # conv_in consumes the 8 latent+concat channels zero-padded to one 64-wide K slice
 
 
@@ -276,6 +279,8 @@ class UNetModel(nn.Module):
 
         def tblock(p, cross):
             d = {"attn1": attn_self(p + ".attn1"), "ff1": lin(p + ".ff.net.0.proj"), "ff2": lin(p + ".ff.net.2")}
+            if d["ff2"].N == 320 and d["ff1"].N == 2560:          # dim 320: the fused FeedForward kernel's weight order
+                d["ff2p"] = ops.ff2_permuted(self._p(p + ".ff.net.2.weight"), device)
             for n in ("norm1", "norm2", "norm3"):
                 d[n] = (f32(f"{p}.{n}.weight"), f32(f"{p}.{n}.bias"))
             if cross:
@@ -405,6 +410,9 @@ class UNetModel(nn.Module):
     def _ff(self, Wb, h, tag="ln"):
         A = self._arena
         n = self._ln(h, Wb["norm3"], tag)
+        if "ff2p" in Wb and _FF_FUSED and h.shape[0] >= 32768:
+            # dim 320: ff1 -> GEGLU -> ff2 (+ residual) in one kernel; the [rows, 1280] intermediate stays on the CU
+            return ops.ff_geglu_fused320(n, Wb["ff1"], Wb["ff2p"], Wb["ff2"].bias, h, residual=h)
         mid = ops.gemm(n, Wb["ff1"], A.get("ffmid", h.shape[0], Wb["ff1"].N // 2, device=h.device), geglu=True)
         return ops.gemm(mid, Wb["ff2"], h, residual=h)
 

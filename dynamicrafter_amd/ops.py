@@ -386,6 +386,38 @@ def temporal_attn(qkv, o, *, B, T, HW, heads, scale):
     return o
 
 
+def ff2_permuted(weight, device):
+    """ff.net.2.weight [320, 1280] -> bf16 [384, 1280] in the k order dc_ff_geglu_fused320 reads: inside every
+    32-channel chunk, position 16 s + 8 h + e holds channel 8 (2 s + e // 4) + 4 h + e % 4."""
+    w = weight.detach()
+    N, K = w.shape
+    pos = torch.arange(32)
+    s_, h_, e_ = pos // 16, (pos // 8) % 2, pos % 8
+    chan = 8 * (2 * s_ + e_ // 4) + 4 * h_ + e_ % 4
+    idx = (torch.arange(K // 32)[:, None] * 32 + chan[None, :]).reshape(-1)
+    n_pad = (N + 127) // 128 * 128
+    out = torch.zeros((n_pad, K), dtype=_BF16, device=device)
+    out[:N] = w[:, idx].to(device=device, dtype=_BF16)
+    return out
+
+
+def ff_geglu_fused320(x, pw1, w2p, b2, out, residual=None):
+    """out = FeedForward_GEGLU(x) (+ residual) for dim 320 in one launch; pw1 = PackedWeight.linear(ff.net.0.proj)."""
+    _rows(x, "x"); _rows(out, "out")
+    M = x.shape[0]
+    if pw1.K != 320 or pw1.N != 2560 or pw1.bias is None or tuple(w2p.shape[1:]) != (1280,) or w2p.shape[0] < 320:
+        raise ValueError("ff_geglu_fused320: dim must be 320 (ff1 [2560, 320] with bias, ff2 [320, 1280])")
+    _need_rows(x, M, 320, "x"); _need_rows(out, M, 320, "out")
+    if residual is not None:
+        _rows(residual, "residual"); _need_rows(residual, M, 320, "residual")
+    flops = 2.0 * M * (2560 + 1280) * 320
+    nbytes = 2.0 * M * 320 * (3 if residual is not None else 2) + 2.0 * (2560 * 320 + 320 * 1280)
+    _launch("ff_geglu_fused320", flops, nbytes, _hip.lib().dc_ff_geglu_fused320, _ptr(x), x.stride(0), _ptr(pw1.w), _ptr(pw1.bias),
+            _ptr(w2p), _ptr(b2), _ptr(residual), 0 if residual is None else residual.stride(0), _ptr(out), out.stride(0), M,
+            stream_ptr())
+    return out
+
+
 def attn_small(q, k, v, o, *, batch, heads, Lq, Lk, d, scale, causal=False):
     """Any-head-width attention (CLIP towers): q/o rows [batch*Lq, >= heads*d], k/v rows [batch*Lk, >= heads*d]."""
     for t, n in ((q, "q"), (k, "k"), (v, "v"), (o, "o")):

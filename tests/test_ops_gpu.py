@@ -641,3 +641,34 @@ def test_cross_attn_dual_vs_torch(ops, B, heads, Lq, nt, ni, s2):
     ops.flash_attn(q, kv[nt:, 2 * Cc:3 * Cc], kv[nt:, 3 * Cc:], o2, batch=B, heads=heads, Lq=Lq, Lk=ni, scale=0.125,
                    kv_bstride=Lc, accumulate=True, acc_scale=s2)
     assert rel_l2(o, o2) < 6e-3
+
+
+@pytest.mark.parametrize("M", [128 * 5, 1000, 40000])
+def test_ff_geglu_fused320_vs_torch(ops, M):
+    """ff1 -> GEGLU -> ff2 (+ residual) in one kernel (dim 320) vs fp32 torch and vs the two-GEMM path."""
+    g = torch.Generator().manual_seed(21)
+    w1 = torch.randn(2560, 320, generator=g) * 320 ** -0.5
+    b1 = torch.randn(2560, generator=g) * 0.1
+    w2 = torch.randn(320, 1280, generator=g) * 1280 ** -0.5
+    b2 = torch.randn(320, generator=g) * 0.1
+    x = bf(torch.randn(M, 320, generator=g))
+    res = bf(torch.randn(M, 320, generator=g))
+    pw1 = ops.PackedWeight.linear(w1, b1, DEV)
+    pw2 = ops.PackedWeight.linear(w2, b2, DEV)
+    w2p = ops.ff2_permuted(w2, DEV)
+    out = torch.empty(M, 320, dtype=torch.bfloat16, device=DEV)
+    ops.ff_geglu_fused320(x.to(DEV), pw1, w2p, pw2.bias, out, residual=res.to(DEV))
+    xf = x.float()
+    hmid = xf @ bf(w1).float().T + b1
+    val, gate = hmid[:, :1280], hmid[:, 1280:]
+    ref = (bf(val * F.gelu(gate)).float() @ bf(w2).float().T + b2) + res.float()
+    assert rel_l2(out, ref) < 4e-3
+    mid = torch.empty(M, 1280, dtype=torch.bfloat16, device=DEV)
+    ops.gemm(x.to(DEV), pw1, mid, geglu=True)
+    out2 = torch.empty_like(out)
+    ops.gemm(mid, pw2, out2, residual=res.to(DEV))
+    assert rel_l2(out, out2) < 4e-3
+    # in place (out aliases the residual), as the transformer blocks call it
+    h = res.to(DEV).clone()
+    ops.ff_geglu_fused320(x.to(DEV), pw1, w2p, pw2.bias, h, residual=h)
+    assert torch.equal(h, out)

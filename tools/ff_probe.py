@@ -1,0 +1,25 @@
+"""Fused FeedForward (dim 320) vs the ff1(GEGLU) + ff2 GEMM pair at the level-0 row count. usage: ff_probe.py"""
+import os, sys, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from dynamicrafter_amd import ops
+DEV = "cuda:0"
+M = int(sys.argv[1]) if len(sys.argv) > 1 else 294912
+g = torch.Generator().manual_seed(1)
+w1 = torch.randn(2560, 320, generator=g) * 320 ** -0.5; b1 = torch.randn(2560, generator=g) * 0.1
+w2 = torch.randn(320, 1280, generator=g) * 1280 ** -0.5; b2 = torch.randn(320, generator=g) * 0.1
+pw1 = ops.PackedWeight.linear(w1, b1, DEV); pw2 = ops.PackedWeight.linear(w2, b2, DEV); w2p = ops.ff2_permuted(w2, DEV)
+x = torch.randn(M, 320, device=DEV).to(torch.bfloat16); h = torch.randn(M, 320, device=DEV).to(torch.bfloat16)
+mid = torch.empty(M, 1280, dtype=torch.bfloat16, device=DEV)
+def pair():
+    ops.gemm(x, pw1, mid, geglu=True); ops.gemm(mid, pw2, h, residual=h)
+def fused():
+    ops.ff_geglu_fused320(x, pw1, w2p, pw2.bias, h, residual=h)
+for name, fn in (("pair", pair), ("fused", fused), ("pair", pair), ("fused", fused)):
+    for _ in range(2): fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(10): fn()
+    e1.record(); torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) / 10 * 1e3
+    print(f"{name:6s} M={M}: {us:8.1f} us  {2.0 * M * 3840 * 320 / us / 1e6:7.1f} TF/s", flush=True)
