@@ -66,8 +66,12 @@ struct FfParams {
     const bf16_t* R; int ldr;    // residual or nullptr
     bf16_t* O; int ldo;
     int M;
+    const float* ln_g;           // optional LayerNorm in front (norm3 of BasicTransformerBlock): X is normalised in registers
+    const float* ln_b;
+    float ln_eps;
 };
 
+template <bool LN>
 __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1)))
 void ff_geglu_fused320_kernel(const FfParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -184,6 +188,45 @@ void ff_geglu_fused320_kernel(const FfParams p) {
             const bf16_t* xr = p.X + (size_t)mr * p.ldx + fh * 8;
 #pragma unroll
             for (int kk = 0; kk < FD / 16; ++kk) xf[kk] = *reinterpret_cast<const bf16x8_t*>(xr + kk * 16);
+            if constexpr (LN) {
+                // LayerNorm over the row (attention.py:225-227 norm3, eps 1e-5), two-pass in registers: lanes (fr, 0) and
+                // (fr, 1) hold the two halves of row fr; the result is rounded to bf16 exactly where the stand-alone
+                // LayerNorm kernel rounds its output.
+                float sum = 0.f;
+#pragma unroll
+                for (int kk = 0; kk < FD / 16; ++kk) {
+                    const u32x4_t w = __builtin_bit_cast(u32x4_t, xf[kk]);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) sum += __uint_as_float(w[e] << 16) + __uint_as_float(w[e] & 0xffff0000u);
+                }
+                sum += __shfl_xor(sum, 32, 64);
+                const float mean = sum * (1.0f / FD);
+                float q = 0.f;
+#pragma unroll
+                for (int kk = 0; kk < FD / 16; ++kk) {
+                    const u32x4_t w = __builtin_bit_cast(u32x4_t, xf[kk]);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float d0 = __uint_as_float(w[e] << 16) - mean, d1 = __uint_as_float(w[e] & 0xffff0000u) - mean;
+                        q += d0 * d0 + d1 * d1;
+                    }
+                }
+                q += __shfl_xor(q, 32, 64);
+                const float rstd = rsqrtf(q * (1.0f / FD) + p.ln_eps);
+#pragma unroll
+                for (int kk = 0; kk < FD / 16; ++kk) {
+                    const u32x4_t w = __builtin_bit_cast(u32x4_t, xf[kk]);
+                    const int c0 = kk * 16 + fh * 8;
+                    const float4 g0 = *reinterpret_cast<const float4*>(p.ln_g + c0), g1 = *reinterpret_cast<const float4*>(p.ln_g + c0 + 4);
+                    const float4 b0 = *reinterpret_cast<const float4*>(p.ln_b + c0), b1 = *reinterpret_cast<const float4*>(p.ln_b + c0 + 4);
+                    u32x4_t o;
+                    o[0] = pack_bf2((__uint_as_float(w[0] << 16) - mean) * rstd * g0.x + b0.x, (__uint_as_float(w[0] & 0xffff0000u) - mean) * rstd * g0.y + b0.y);
+                    o[1] = pack_bf2((__uint_as_float(w[1] << 16) - mean) * rstd * g0.z + b0.z, (__uint_as_float(w[1] & 0xffff0000u) - mean) * rstd * g0.w + b0.w);
+                    o[2] = pack_bf2((__uint_as_float(w[2] << 16) - mean) * rstd * g1.x + b1.x, (__uint_as_float(w[2] & 0xffff0000u) - mean) * rstd * g1.y + b1.y);
+                    o[3] = pack_bf2((__uint_as_float(w[3] << 16) - mean) * rstd * g1.z + b1.z, (__uint_as_float(w[3] & 0xffff0000u) - mean) * rstd * g1.w + b1.w);
+                    xf[kk] = __builtin_bit_cast(bf16x8_t, o);
+                }
+            }
         }
         f32x16_t acc[FD / 32];
 #pragma unroll
@@ -326,24 +369,29 @@ void ff_geglu_fused320_kernel(const FfParams p) {
 
 }  // namespace
 
-extern "C" int dc_ff_geglu_fused320(const uint16_t* x, int ldx, const uint16_t* w1, const float* b1, const uint16_t* w2p,
-                                    const float* b2, const uint16_t* residual, int ldr, uint16_t* out, int ldo, int M,
-                                    void* stream_) {
-    if (!x || !w1 || !b1 || !w2p || !b2 || !out) return DC_ERR_ARG;
+extern "C" int dc_ff_geglu_fused320(const uint16_t* x, int ldx, const float* ln_gamma, const float* ln_beta, float ln_eps,
+                                    const uint16_t* w1, const float* b1, const uint16_t* w2p, const float* b2,
+                                    const uint16_t* residual, int ldr, uint16_t* out, int ldo, int M, void* stream_) {
+    if (!x || !w1 || !b1 || !w2p || !b2 || !out || ((ln_gamma == nullptr) != (ln_beta == nullptr))) return DC_ERR_ARG;
     if (M < 1 || ldx % 8 || ldo % 8 || (residual && ldr % 8)) return DC_ERR_SHAPE;
     if (((uintptr_t)x | (uintptr_t)out | (uintptr_t)w1 | (uintptr_t)w2p | (uintptr_t)(residual ? residual : out)) % 16) return DC_ERR_SHAPE;
     static bool configured = false;
     if (!configured) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ff_geglu_fused320_kernel),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ff_geglu_fused320_kernel<false>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, FF_LDS);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ff_geglu_fused320_kernel<true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, FF_LDS);
         if (e != hipSuccess) return (int)e;
         configured = true;
     }
     FfParams p;
     p.X = x; p.ldx = ldx; p.W1 = w1; p.b1 = b1; p.W2p = w2p; p.b2 = b2; p.R = residual; p.ldr = ldr; p.O = out; p.ldo = ldo;
-    p.M = M;
+    p.M = M; p.ln_g = ln_gamma; p.ln_b = ln_beta; p.ln_eps = ln_eps;
     const int tiles = (M + FBM - 1) / FBM;
-    hipLaunchKernelGGL(ff_geglu_fused320_kernel, dim3(tiles < 256 ? tiles : 256), dim3(256), FF_LDS, (hipStream_t)stream_, p);
+    const dim3 grid(tiles < 256 ? tiles : 256);
+    if (ln_gamma) hipLaunchKernelGGL(ff_geglu_fused320_kernel<true>, grid, dim3(256), FF_LDS, (hipStream_t)stream_, p);
+    else hipLaunchKernelGGL(ff_geglu_fused320_kernel<false>, grid, dim3(256), FF_LDS, (hipStream_t)stream_, p);
     DC_CHECK_LAUNCH();
     return 0;
 }

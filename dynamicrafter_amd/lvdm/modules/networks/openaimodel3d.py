@@ -409,10 +409,11 @@ class UNetModel(nn.Module):
 
     def _ff(self, Wb, h, tag="ln"):
         A = self._arena
-        n = self._ln(h, Wb["norm3"], tag)
         if "ff2p" in Wb and _FF_FUSED and h.shape[0] >= 32768:
-            # dim 320: ff1 -> GEGLU -> ff2 (+ residual) in one kernel; the [rows, 1280] intermediate stays on the CU
-            return ops.ff_geglu_fused320(n, Wb["ff1"], Wb["ff2p"], Wb["ff2"].bias, h, residual=h)
+            # dim 320: x = ff(norm3(x)) + x in ONE kernel - LayerNorm in registers, ff1 -> GEGLU -> ff2, residual add; the
+            # normalised copy and the [rows, 1280] intermediate never reach HBM
+            return ops.ff_geglu_fused320(h, Wb["ff1"], Wb["ff2p"], Wb["ff2"].bias, h, residual=h, ln=Wb["norm3"], ln_eps=1e-5)
+        n = self._ln(h, Wb["norm3"], tag)
         mid = ops.gemm(n, Wb["ff1"], A.get("ffmid", h.shape[0], Wb["ff1"].N // 2, device=h.device), geglu=True)
         return ops.gemm(mid, Wb["ff2"], h, residual=h)
 

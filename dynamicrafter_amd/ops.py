@@ -401,8 +401,9 @@ def ff2_permuted(weight, device):
     return out
 
 
-def ff_geglu_fused320(x, pw1, w2p, b2, out, residual=None):
-    """out = FeedForward_GEGLU(x) (+ residual) for dim 320 in one launch; pw1 = PackedWeight.linear(ff.net.0.proj)."""
+def ff_geglu_fused320(x, pw1, w2p, b2, out, residual=None, ln=None, ln_eps=1e-5):
+    """out = FeedForward_GEGLU(LayerNorm(x) if ln else x) (+ residual) for dim 320 in one launch; pw1 =
+    PackedWeight.linear(ff.net.0.proj); ln = (gamma, beta) fp32 or None."""
     _rows(x, "x"); _rows(out, "out")
     M = x.shape[0]
     if pw1.K != 320 or pw1.N != 2560 or pw1.bias is None or tuple(w2p.shape[1:]) != (1280,) or w2p.shape[0] < 320:
@@ -410,9 +411,12 @@ def ff_geglu_fused320(x, pw1, w2p, b2, out, residual=None):
     _need_rows(x, M, 320, "x"); _need_rows(out, M, 320, "out")
     if residual is not None:
         _rows(residual, "residual"); _need_rows(residual, M, 320, "residual")
+    if ln is not None:
+        _need(ln[0], 320, "ln gamma"); _need(ln[1], 320, "ln beta")
     flops = 2.0 * M * (2560 + 1280) * 320
     nbytes = 2.0 * M * 320 * (3 if residual is not None else 2) + 2.0 * (2560 * 320 + 320 * 1280)
-    _launch("ff_geglu_fused320", flops, nbytes, _hip.lib().dc_ff_geglu_fused320, _ptr(x), x.stride(0), _ptr(pw1.w), _ptr(pw1.bias),
+    _launch("ff_geglu_fused320", flops, nbytes, _hip.lib().dc_ff_geglu_fused320, _ptr(x), x.stride(0),
+            _ptr(None if ln is None else ln[0]), _ptr(None if ln is None else ln[1]), ln_eps, _ptr(pw1.w), _ptr(pw1.bias),
             _ptr(w2p), _ptr(b2), _ptr(residual), 0 if residual is None else residual.stride(0), _ptr(out), out.stride(0), M,
             stream_ptr())
     return out

@@ -184,14 +184,17 @@ int dc_cross_attn_dual_d64(const uint16_t* q, const uint16_t* k, const uint16_t*
                            uint16_t* o, int ldq, int ldkv, int ldo, int batch, int heads, int Lq, int Lk, int Lk2,
                            int64_t q_bstride, int64_t kv_bstride, float scale, float scale2, void* stream);
 
-/* Fused GEGLU FeedForward for dim = 320: out[M,320] = ((x W1v^T + b1v) * gelu(x W1g^T + b1g)) W2^T + b2 (+ residual),
- * the [M,1280] intermediate never leaves the CU. x/out/residual: bf16 rows (ld % 8 == 0; residual may alias out).
+/* Fused GEGLU FeedForward for dim = 320: out[M,320] = ((n W1v^T + b1v) * gelu(n W1g^T + b1g)) W2^T + b2 (+ residual),
+ * n = x, or LayerNorm(x; ln_gamma, ln_beta, ln_eps) when ln_gamma != NULL (rounded to bf16 like dc_layernorm's output);
+ * the [M,1280] intermediate never leaves the CU. x/out/residual: bf16 rows (ld % 8 == 0; residual may alias out and x).
  * w1: ff.net.0.proj.weight as dc_gemm_conv takes it, bf16 [>= 2560][320] (rows 0..1279 value, 1280..2559 gate), b1 fp32
  * [2560]; w2p: ff.net.2.weight bf16 [>= 320][1280] with the K order permuted inside every 32-channel chunk: position
  * 16 s + 8 h + e of a chunk holds channel 8 (2 s + e / 4) + 4 h + e % 4 (s, h in {0,1}, e in 0..7); b2 fp32 [320].
- * replaces FeedForward(GEGLU) lvdm/modules/attention.py:415-442 + the residual add of BasicTransformerBlock :246 */
-int dc_ff_geglu_fused320(const uint16_t* x, int ldx, const uint16_t* w1, const float* b1, const uint16_t* w2p, const float* b2,
-                         const uint16_t* residual, int ldr, uint16_t* out, int ldo, int M, void* stream);
+ * replaces FeedForward(GEGLU) lvdm/modules/attention.py:415-442 with norm3 and the residual add of
+ * BasicTransformerBlock._forward :246 (x = ff(norm3(x)) + x) */
+int dc_ff_geglu_fused320(const uint16_t* x, int ldx, const float* ln_gamma, const float* ln_beta, float ln_eps,
+                         const uint16_t* w1, const float* b1, const uint16_t* w2p, const float* b2, const uint16_t* residual,
+                         int ldr, uint16_t* out, int ldo, int M, void* stream);
 
 /* ---- conditioning encoders (once per clip) ---------------------------------------------------- */
 

@@ -672,3 +672,12 @@ def test_ff_geglu_fused320_vs_torch(ops, M):
     h = res.to(DEV).clone()
     ops.ff_geglu_fused320(x.to(DEV), pw1, w2p, pw2.bias, h, residual=h)
     assert torch.equal(h, out)
+    # with the LayerNorm in front folded in: x = ff(LN(x)) + x, input = residual = output buffer
+    gam = 1 + 0.2 * torch.randn(320, generator=g); bet = 0.3 * torch.randn(320, generator=g)
+    h = (x * 1.7 + 0.3).to(torch.bfloat16).to(DEV)
+    n_ref = torch.empty_like(h)
+    ops.layernorm(h, n_ref, gam.to(DEV), bet.to(DEV), 1e-5)
+    want = torch.empty_like(h)
+    ops.ff_geglu_fused320(n_ref, pw1, w2p, pw2.bias, want, residual=h)
+    ops.ff_geglu_fused320(h, pw1, w2p, pw2.bias, h, residual=h, ln=(gam.to(DEV), bet.to(DEV)))
+    assert rel_l2(h, want) < 2e-3                      # same rounding points; the row statistics sum in a different order

@@ -14,7 +14,13 @@ def pair():
     ops.gemm(x, pw1, mid, geglu=True); ops.gemm(mid, pw2, h, residual=h)
 def fused():
     ops.ff_geglu_fused320(x, pw1, w2p, pw2.bias, h, residual=h)
-for name, fn in (("pair", pair), ("fused", fused), ("pair", pair), ("fused", fused)):
+gam = torch.ones(320, device=DEV); bet = torch.zeros(320, device=DEV)
+def ln_pair():
+    ops.layernorm(h, x, gam, bet, 1e-5); pair()
+def ln_fused():
+    ops.ff_geglu_fused320(h, pw1, w2p, pw2.bias, h, residual=h, ln=(gam, bet))
+for name, fn in (("pair", pair), ("fused", fused), ("ln+pair", ln_pair), ("lnfused", ln_fused), ("pair", pair), ("fused", fused),
+                 ("ln+pair", ln_pair), ("lnfused", ln_fused)):
     for _ in range(2): fn()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -22,4 +28,4 @@ for name, fn in (("pair", pair), ("fused", fused), ("pair", pair), ("fused", fus
     for _ in range(10): fn()
     e1.record(); torch.cuda.synchronize()
     us = e0.elapsed_time(e1) / 10 * 1e3
-    print(f"{name:6s} M={M}: {us:8.1f} us  {2.0 * M * 3840 * 320 / us / 1e6:7.1f} TF/s", flush=True)
+    print(f"{name:8s} M={M}: {us:8.1f} us  {2.0 * M * 3840 * 320 / us / 1e6:7.1f} TF/s", flush=True)
