@@ -36,10 +36,20 @@ constexpr int FNCH = FM / FCH;     // 40 chunks
 constexpr int FBM = 128;           // rows per workgroup tile
 constexpr int W1_STAGE = 64 * FD * 2;          // 40 KB: 5 K tiles of [64 rows][128 B]
 constexpr int W2_STAGE = FD * FCH * 2;         // 20 KB: [320 rows][64 B]
-constexpr int FF_LDS = 2 * W1_STAGE + 2 * W2_STAGE + 4 * 2048 + 2 * FM * 4;    // rings + epilogue patches + b1 (fp32)
+constexpr int W2_RING = 3;
+constexpr int FF_LDS = 2 * W1_STAGE + W2_RING * W2_STAGE + 4 * 2048 + 2 * FM * 4;    // rings + epilogue patches + b1 (fp32)
+static_assert(FF_LDS <= 160 * 1024, "LDS");
 
 typedef __attribute__((address_space(3))) char lds_char_t;
+typedef const volatile __attribute__((address_space(3))) bf16x8_t lds_vfrag_t;   // pinned LDS fragment load (see PD)
 __device__ __attribute__((aligned(16))) uint32_t g_zero_ff[8];
+#ifdef DC_FF_STAMPS          // tool build only (tools/ff_stamps.py): shader-clock totals of the four parts of a chunk iteration
+__device__ unsigned long long g_ff_stamps[8];
+#define FF_STAMP(i) do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); const unsigned long long t__ = __builtin_readcyclecounter(); \
+                         st_acc[i] += t__ - st_last; st_last = t__; } while (0)
+#else
+#define FF_STAMP(i) do { } while (0)
+#endif
 
 __device__ __forceinline__ int off128(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
 __device__ __forceinline__ int off64(int row, int chunk) { return row * 64 + ((chunk ^ ((row >> 2) & 3)) << 4); }
@@ -81,103 +91,64 @@ void ff_geglu_fused320_kernel(const FfParams p) {
     const int fr = lane & 31, fh = lane >> 5;
     const unsigned lds_base = (unsigned)(unsigned long)((lds_char_t*)smem);
     char* const w1s = smem;                              // 2 x W1_STAGE
-    char* const w2s = smem + 2 * W1_STAGE;               // 2 x W2_STAGE
-    char* const ebuf = smem + 2 * W1_STAGE + 2 * W2_STAGE + wave * 2048;
+    char* const w2s = smem + 2 * W1_STAGE;               // W2_RING x W2_STAGE
+    char* const ebuf = smem + 2 * W1_STAGE + W2_RING * W2_STAGE + wave * 2048;
 
     const int tiles = (p.M + FBM - 1) / FBM;
     // ff1 bias (2560 floats) staged once: a global load per chunk sat ~500 cycles in front of every GEGLU
-    float* const b1s = reinterpret_cast<float*>(smem + 2 * W1_STAGE + 2 * W2_STAGE + 4 * 2048);
+    float* const b1s = reinterpret_cast<float*>(smem + 2 * W1_STAGE + W2_RING * W2_STAGE + 4 * 2048);
     for (int i = tid; i < 2 * FM; i += 256) b1s[i] = p.b1[i];
     __syncthreads();
 
-    // LDS-DMA of chunk j: W1 rows (10 instructions of 8 rows x 128 B per wave) and W2 columns (5 instructions of 16 rows x
-    // 64 B per wave), each into stage (j & 1) of its own two-deep ring. Addressing = 64-bit SCALAR base (SALU, free next
-    // to the vector pipes) + one of three per-lane 32-bit offsets computed once per kernel; m0 (the LDS destination)
-    // advances by 1 KB per instruction inside one asm block. (Per-lane 64-bit pointer arithmetic and an m0 save /
-    // restore around every instruction cost 1100 cycles per chunk: 15 % of the kernel.)
-    const unsigned voff1[2] = {
-        (unsigned)((lane >> 3) * (FD * 2) + (((lane & 7) ^ ((0 * 4 + (lane >> 4)) & 7)) << 4)),     // 8-row group index even
-        (unsigned)((lane >> 3) * (FD * 2) + (((lane & 7) ^ ((1 * 4 + (lane >> 4)) & 7)) << 4))};    // odd
-    const unsigned voff2 = (unsigned)((lane >> 2) * (FM * 2) + (((lane & 3) ^ ((lane >> 4) & 3)) << 4));
-    auto issue_w1 = [&](int j) __attribute__((always_inline)) {
-        const unsigned dst0 = lds_base + (j & 1) * W1_STAGE + wave * 10 * 1024;
-        uint64_t sb[10];
+    // LDS-DMA of chunk j: W1 rows (10 pieces of 8 rows x 128 B per wave) into stage j & 1 of a two-deep ring, W2 columns
+    // (5 pieces of 16 rows x 64 B per wave) into stage j % 3 of a three-deep ring. One piece = one
+    // global_load_lds_dwordx4 = 1 KB. Addressing: a 64-bit SCALAR base per ring and chunk + a per-lane 32-bit offset
+    // per piece, computed once per kernel (15 VGPRs). A piece costs the issuing wave ~60 cycles whatever surrounds it,
+    // so the main loop places the pieces one by one behind the MFMAs of phase 2 (the matrix pipe works them off
+    // meanwhile) instead of in a block at the top of the iteration (1150 cycles per chunk, a quarter of the kernel).
+    unsigned vo1[10], vo2[5];
 #pragma unroll
-        for (int i = 0; i < 10; ++i) {
-            const int u = wave * 10 + i;                 // (K tile t, 8-row group g): LDS offset u * 1024
-            const int t = u >> 3, g = u & 7;             // rows g*8 .. +7 of the 64-row chunk: g < 4 value, else gate
-            const int wrow = g < 4 ? j * FCH + g * 8 : FM + j * FCH + (g - 4) * 8;
-            sb[i] = (uint64_t)(uintptr_t)p.W1 + (uint64_t)wrow * (FD * 2) + t * 128;
-        }
+    for (int i = 0; i < 10; ++i) {
+        const int u = wave * 10 + i;                     // (K tile t, 8-row group g): LDS offset u * 1024
+        const int t = u >> 3, g = u & 7;                 // rows g*8 .. +7 of the 64-row chunk: g < 4 value, else gate
+        const int row = (g < 4 ? g * 8 : FM + (g - 4) * 8) + (lane >> 3);
+        vo1[i] = (unsigned)(row * (FD * 2) + t * 128 + (((lane & 7) ^ ((g * 4 + (lane >> 4)) & 7)) << 4));
+    }
+#pragma unroll
+    for (int i = 0; i < 5; ++i)                          // 16-row group wave*5 + i of the 320 output channels
+        vo2[i] = (unsigned)(((wave * 5 + i) * 16 + (lane >> 2)) * (FM * 2) + (((lane & 3) ^ ((lane >> 4) & 3)) << 4));
+#pragma unroll
+    for (int i = 0; i < 10; ++i) asm volatile("" : "+v"(vo1[i]));    // opaque: or hipcc re-derives the wave-uniform parts
+#pragma unroll                                                       // in the main loop (5 scalar instructions per piece)
+    for (int i = 0; i < 5; ++i) asm volatile("" : "+v"(vo2[i]));
+    auto dma_piece = [&](unsigned lds_dst, unsigned voff, uint64_t sbase) __attribute__((always_inline)) {
         unsigned keep;
         asm volatile(
-            "s_mov_b32 %[keep], m0\n\t"
-            "s_mov_b32 m0, %[d0]\n\t"
+            "s_mov_b32 %0, m0\n\t"
+            "s_mov_b32 m0, %1\n\t"
             "s_nop 0\n\t"
-            "global_load_lds_dwordx4 %[va], %[s0]\n\t"
-            "s_add_u32 m0, m0, 0x400\n\t"
-            "s_nop 0\n\t"
-            "global_load_lds_dwordx4 %[vb], %[s1]\n\t"
-            "s_add_u32 m0, m0, 0x400\n\t"
-            "s_nop 0\n\t"
-            "global_load_lds_dwordx4 %[va], %[s2]\n\t"
-            "s_add_u32 m0, m0, 0x400\n\t"
-            "s_nop 0\n\t"
-            "global_load_lds_dwordx4 %[vb], %[s3]\n\t"
-            "s_add_u32 m0, m0, 0x400\n\t"
-            "s_nop 0\n\t"
-            "global_load_lds_dwordx4 %[va], %[s4]\n\t"
-            "s_add_u32 m0, m0, 0x400\n\t"
-            "s_nop 0\n\t"
-            "global_load_lds_dwordx4 %[vb], %[s5]\n\t"
-            "s_add_u32 m0, m0, 0x400\n\t"
-            "s_nop 0\n\t"
-            "global_load_lds_dwordx4 %[va], %[s6]\n\t"
-            "s_add_u32 m0, m0, 0x400\n\t"
-            "s_nop 0\n\t"
-            "global_load_lds_dwordx4 %[vb], %[s7]\n\t"
-            "s_add_u32 m0, m0, 0x400\n\t"
-            "s_nop 0\n\t"
-            "global_load_lds_dwordx4 %[va], %[s8]\n\t"
-            "s_add_u32 m0, m0, 0x400\n\t"
-            "s_nop 0\n\t"
-            "global_load_lds_dwordx4 %[vb], %[s9]\n\t"
-            "s_mov_b32 m0, %[keep]"
-            : [keep] "=&s"(keep)
-            : [d0] "s"(dst0), [va] "v"(voff1[0]), [vb] "v"(voff1[1]), [s0] "s"(sb[0]), [s1] "s"(sb[1]), [s2] "s"(sb[2]),
-              [s3] "s"(sb[3]), [s4] "s"(sb[4]), [s5] "s"(sb[5]), [s6] "s"(sb[6]), [s7] "s"(sb[7]), [s8] "s"(sb[8]), [s9] "s"(sb[9])
-            : "memory", "scc");
+            "global_load_lds_dwordx4 %2, %3\n\t"
+            "s_mov_b32 m0, %0"
+            : "=&s"(keep)
+            : "s"(lds_dst), "v"(voff), "s"(sbase)
+            : "memory");
     };
-    auto issue_w2 = [&](int j) __attribute__((always_inline)) {
-        const unsigned dst0 = lds_base + 2 * W1_STAGE + (j & 1) * W2_STAGE + wave * 5 * 1024;
-        uint64_t sb[5];
+    auto w1_base = [&](int j) { return (uint64_t)(uintptr_t)p.W1 + (uint64_t)j * (FCH * FD * 2); };
+    auto w2_base = [&](int j) { return (uint64_t)(uintptr_t)p.W2p + (uint64_t)j * (FCH * 2); };
+    auto w1_dst = [&](int j, int i) { return lds_base + (j & 1) * W1_STAGE + (wave * 10 + i) * 1024; };
+    auto w2_dst = [&](int stage, int i) { return lds_base + 2 * W1_STAGE + stage * W2_STAGE + (wave * 5 + i) * 1024; };
+    auto issue_w1 = [&](int j) __attribute__((always_inline)) {
 #pragma unroll
-        for (int i = 0; i < 5; ++i)                       // 16-row group wave*5 + i of the 320 output channels
-            sb[i] = (uint64_t)(uintptr_t)p.W2p + (uint64_t)((wave * 5 + i) * 16) * (FM * 2) + j * (FCH * 2);
-        unsigned keep;
-        asm volatile(
-            "s_mov_b32 %[keep], m0\n\t"
-            "s_mov_b32 m0, %[d0]\n\t"
-            "s_nop 0\n\t"
-            "global_load_lds_dwordx4 %[va], %[s0]\n\t"
-            "s_add_u32 m0, m0, 0x400\n\t"
-            "s_nop 0\n\t"
-            "global_load_lds_dwordx4 %[va], %[s1]\n\t"
-            "s_add_u32 m0, m0, 0x400\n\t"
-            "s_nop 0\n\t"
-            "global_load_lds_dwordx4 %[va], %[s2]\n\t"
-            "s_add_u32 m0, m0, 0x400\n\t"
-            "s_nop 0\n\t"
-            "global_load_lds_dwordx4 %[va], %[s3]\n\t"
-            "s_add_u32 m0, m0, 0x400\n\t"
-            "s_nop 0\n\t"
-            "global_load_lds_dwordx4 %[va], %[s4]\n\t"
-            "s_mov_b32 m0, %[keep]"
-            : [keep] "=&s"(keep)
-            : [d0] "s"(dst0), [va] "v"(voff2), [s0] "s"(sb[0]), [s1] "s"(sb[1]), [s2] "s"(sb[2]), [s3] "s"(sb[3]), [s4] "s"(sb[4])
-            : "memory", "scc");
+        for (int i = 0; i < 10; ++i) dma_piece(w1_dst(j, i), vo1[i], w1_base(j));
+    };
+    auto issue_w2 = [&](int j, int stage) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < 5; ++i) dma_piece(w2_dst(stage, i), vo2[i], w2_base(j));
     };
 
+#ifdef DC_FF_STAMPS
+    unsigned long long st_acc[5] = {0, 0, 0, 0, 0}, st_last = 0;
+#endif
     for (int tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
         const int m0 = tile * FBM + wave * 32;
         // ---- X fragments of this wave's 32 rows (B operand: lane (row fr, half fh) holds k = 16 kk + 8 fh .. + 7)
@@ -234,8 +205,12 @@ void ff_geglu_fused320_kernel(const FfParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[nb][r] = 0.f;
 
-        constexpr int PD = 4;           // LDS fragments are read PD steps ahead of the MFMA that consumes them (one wave per
-                                        // SIMD: nothing else hides the LDS latency)
+        // LDS fragments are read PD k steps (phase 1: two fragments each) / PD2 fragments (phase 2) ahead of the MFMA that
+        // consumes them - one wave per SIMD: nothing else hides the LDS latency. The loads are VOLATILE and every
+        // consumer passes through an empty volatile asm: that pins the distance. With plain loads hipcc sank each
+        // read to just in front of its MFMA to save registers (window of one, `s_waitcnt lgkmcnt(0)` per MFMA pair),
+        // and both MFMA phases ran at 64 cycles per MFMA instead of 32.
+        constexpr int PD = 4, PD2 = 8;
         // phase 1 of chunk c: value / gate pre-activations of its 32 channels for this wave's 32 rows
         auto phase1 = [&](int c, f32x16_t& av, f32x16_t& ag) __attribute__((always_inline)) {
             const char* s1 = w1s + (c & 1) * W1_STAGE;
@@ -244,15 +219,16 @@ void ff_geglu_fused320_kernel(const FfParams p) {
             bf16x8_t wv[PD], wg[PD];
             auto rd1 = [&](int kk, int slot) __attribute__((always_inline)) {
                 const char* kt = s1 + (kk >> 2) * 8192;
-                wv[slot] = *reinterpret_cast<const bf16x8_t*>(kt + off128(fr, (kk & 3) * 2 + fh));
-                wg[slot] = *reinterpret_cast<const bf16x8_t*>(kt + off128(32 + fr, (kk & 3) * 2 + fh));
+                wv[slot] = *(lds_vfrag_t*)((lds_char_t*)kt + off128(fr, (kk & 3) * 2 + fh));
+                wg[slot] = *(lds_vfrag_t*)((lds_char_t*)kt + off128(32 + fr, (kk & 3) * 2 + fh));
             };
 #pragma unroll
             for (int kk = 0; kk < PD; ++kk) rd1(kk, kk);
 #pragma unroll
             for (int kk = 0; kk < FD / 16; ++kk) {
-                const bf16x8_t cv = wv[kk % PD], cg = wg[kk % PD];
+                bf16x8_t cv = wv[kk % PD], cg = wg[kk % PD];
                 if (kk + PD < FD / 16) rd1(kk + PD, kk % PD);
+                asm volatile("" : "+v"(cv), "+v"(cg));
                 av = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cv, xf[kk], av, 0, 0, 0);
                 ag = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cg, xf[kk], ag, 0, 0, 0);
             }
@@ -279,56 +255,160 @@ void ff_geglu_fused320_kernel(const FfParams p) {
                 pf[s] = __builtin_bit_cast(bf16x8_t, pw);
             }
         };
-        // phase 2 of chunk c: out[row][ch] += P W2c^T (W2 packed in the matching k order)
-        auto phase2 = [&](int c, const bf16x8_t (&pf)[2]) __attribute__((always_inline)) {
-            const char* s2 = w2s + (c & 1) * W2_STAGE;
-            bf16x8_t w2r[PD];
+        // phase 2 of chunk c (W2 ring stage st): out[row][ch] += P W2c^T (W2 packed in the matching k order). DW1 / DW2:
+        // the wave's LDS-DMA pieces of W1(jd + 2) / W2(jd + 1) go out one behind each of the first MFMAs.
+        auto phase2 = [&](int st, const bf16x8_t (&pf)[2], auto DW1, auto DW2, int jd, int st_next) __attribute__((always_inline)) {
+            const char* s2 = w2s + st * W2_STAGE;
+            bf16x8_t w2r[PD2];
             auto rd2 = [&](int idx, int slot) __attribute__((always_inline)) {      // idx = s * 10 + nb
                 const int s = idx / (FD / 32), nb = idx % (FD / 32);
-                w2r[slot] = *reinterpret_cast<const bf16x8_t*>(s2 + off64(nb * 32 + fr, s * 2 + fh));
+                w2r[slot] = *(lds_vfrag_t*)((lds_char_t*)s2 + off64(nb * 32 + fr, s * 2 + fh));
             };
 #pragma unroll
-            for (int i = 0; i < PD; ++i) rd2(i, i);
+            for (int i = 0; i < PD2; ++i) rd2(i, i);
+            const uint64_t b1n = w1_base(jd + 2), b2n = w2_base(jd + 1);
 #pragma unroll
             for (int idx = 0; idx < 2 * (FD / 32); ++idx) {
                 const int s = idx / (FD / 32), nb = idx % (FD / 32);
-                const bf16x8_t cw = w2r[idx % PD];
-                if (idx + PD < 2 * (FD / 32)) rd2(idx + PD, idx % PD);
+                bf16x8_t cw = w2r[idx % PD2];
+                if (idx + PD2 < 2 * (FD / 32)) rd2(idx + PD2, idx % PD2);
+                asm volatile("" : "+v"(cw));
                 acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cw, pf[s], acc[nb], 0, 0, 0);
+                if (DW1.value && idx < 10) dma_piece(w1_dst(jd + 2, idx), vo1[idx], b1n);
+                if (DW2.value && idx >= 10 && idx < 15) dma_piece(w2_dst(st_next, idx - 10), vo2[idx - 10], b2n);
             }
         };
-        // Software pipeline over the 40 chunks: iteration j runs phase 1 of chunk j+1 (MFMA pipe) in the same
-        // instruction stream as the GEGLU arithmetic of chunk j (vector ALU) - independent data, so the MFMAs run
-        // under the erf/exp/convert work - then phase 2 of chunk j. LDS-DMA: W1(j+2) and W2(j+1) are issued at the top
-        // of iteration j (their stages held W1(j) / W2(j-1), both consumed in iteration j-1) and waited for, with
-        // vmcnt(0) + one barrier, at the top of iteration j+1.
+        // phase 1 of chunk c + 1 and the GEGLU of chunk c in ONE hand-interleaved instruction stream. One wave per SIMD
+        // means nothing else overlaps the matrix pipe with the vector ALU, and left to itself hipcc clusters the 40 MFMAs
+        // and the GEGLU arithmetic into separate runs (2400 of 6900 cycles per chunk were GEGLU with an idle matrix pipe;
+        // a sched_group_barrier pipeline over the block is silently dropped, sched_barrier does not order the MFMA
+        // builtins during instruction selection). So the order is pinned with empty volatile asm statements that
+        // "redefine" a value: they are ordered among themselves, the arithmetic in between hangs on them by data
+        // dependence. Per k step: MFMA value | half of the GEGLU of one channel PAIR (packed fp32 math) | MFMA gate.
+        // Even steps run the erf polynomial of pair kk / 2, odd steps its exp, the product and the bf16 pack.
+        auto phase1_geglu = [&](int c, const f32x16_t& cv, const f32x16_t& cg, f32x16_t& nv, f32x16_t& ng, bf16x8_t (&pf)[2])
+            __attribute__((always_inline)) {
+            const char* s1 = w1s + ((c + 1) & 1) * W1_STAGE;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { nv[r] = 0.f; ng[r] = 0.f; }
+            bf16x8_t wv[PD], wg[PD];
+            auto rd1 = [&](int kk, int slot) __attribute__((always_inline)) {
+                const char* kt = s1 + (kk >> 2) * 8192;
+                wv[slot] = *(lds_vfrag_t*)((lds_char_t*)kt + off128(fr, (kk & 3) * 2 + fh));
+                wg[slot] = *(lds_vfrag_t*)((lds_char_t*)kt + off128(32 + fr, (kk & 3) * 2 + fh));
+            };
+#pragma unroll
+            for (int kk = 0; kk < PD; ++kk) rd1(kk, kk);
+            float4 bv, bg, bvn, bgn;                      // ff1 bias of the 4 channels in flight / of the next 4 (LDS latency)
+            bvn = *reinterpret_cast<const float4*>(b1s + c * FCH + 4 * fh);
+            bgn = *reinterpret_cast<const float4*>(b1s + FM + c * FCH + 4 * fh);
+            f32x2_t xg, ww;
+            u32x4_t pw[2];
+#pragma unroll
+            for (int kk = 0; kk < FD / 16; ++kk) {
+                bf16x8_t fv = wv[kk % PD], fg = wg[kk % PD];
+                if (kk + PD < FD / 16) rd1(kk + PD, kk % PD);
+                asm volatile("" : "+v"(fv), "+v"(fg));
+                const int m = kk >> 1;                    // channel pair (values 2m, 2m + 1 of the accumulators)
+                if (kk < 16 && (kk & 3) == 0) {           // accumulator values 4 q .. 4 q + 3 are channels 8 q + 4 fh + i, q = kk / 4
+                    bv = bvn; bg = bgn;
+                    if (kk < 12) {
+                        const int n = c * FCH + 8 * ((kk >> 2) + 1) + 4 * fh;
+                        bvn = *reinterpret_cast<const float4*>(b1s + n);
+                        bgn = *reinterpret_cast<const float4*>(b1s + FM + n);
+                    }
+                }
+                nv = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fv, xf[kk], nv, 0, 0, 0);
+                asm volatile("" : "+a"(nv));
+                // gelu(x) = x/2 (1 + erf(x/sqrt2)) with erf by Abramowitz-Stegun 7.1.26 (as erf_as_f), regrouped to
+                // max(x, 0) - w e:  t = 1 / (1 + 0.3275911 |x| / sqrt2),  w = |x|/2 (a1 t + .. + a5 t^5),  e = exp(-x^2/2)
+                // - 21 vector instructions per channel pair instead of 27 (this stream is issue-bound)
+                if (kk < 16 && !(kk & 1)) {               // polynomial half
+                    f32x2_t g2 = {cg[2 * m], cg[2 * m + 1]};
+                    asm volatile("" : "+v"(g2));
+                    const f32x2_t b2g = (m & 1) ? f32x2_t{bg.z, bg.w} : f32x2_t{bg.x, bg.y};
+                    xg = g2 + b2g;
+                    const f32x2_t d = {fmaf(fabsf(xg.x), 0.3275911f * 0.70710678118654752f, 1.0f),
+                                       fmaf(fabsf(xg.y), 0.3275911f * 0.70710678118654752f, 1.0f)};
+                    const f32x2_t t = {__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
+                    f32x2_t q = t * (0.5f * 1.061405429f) + (0.5f * -1.453152027f);
+                    q = q * t + (0.5f * 1.421413741f);
+                    q = q * t + (0.5f * -0.284496736f);
+                    q = q * t + (0.5f * 0.254829592f);
+                    q = q * t;
+                    ww = f32x2_t{q.x * fabsf(xg.x), q.y * fabsf(xg.y)};
+                    asm volatile("" : "+v"(ww), "+v"(xg));
+                } else if (kk < 16) {                     // exp half, GEGLU product, bf16 pack
+                    f32x2_t v2 = {cv[2 * m], cv[2 * m + 1]};
+                    asm volatile("" : "+v"(v2));
+                    const f32x2_t b2v = (m & 1) ? f32x2_t{bv.z, bv.w} : f32x2_t{bv.x, bv.y};
+                    const f32x2_t a2 = (xg * (-0.5f * 1.4426950408889634f)) * xg;
+                    const f32x2_t e = {__builtin_amdgcn_exp2f(a2.x), __builtin_amdgcn_exp2f(a2.y)};
+                    f32x2_t relu;                         // fmaxf() costs a canonicalising v_max_f32 x, x in front
+                    asm("v_max_f32 %0, 0, %1" : "=v"(relu.x) : "v"(xg.x));
+                    asm("v_max_f32 %0, 0, %1" : "=v"(relu.y) : "v"(xg.y));
+                    const f32x2_t ge = relu - ww * e;
+                    const f32x2_t o = (v2 + b2v) * ge;
+                    unsigned w = pack_bf2(o.x, o.y);
+                    asm volatile("" : "+v"(w));
+                    pw[m >> 2][m & 3] = w;
+                }
+                ng = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fg, xf[kk], ng, 0, 0, 0);
+                asm volatile("" : "+a"(ng));
+            }
+            pf[0] = __builtin_bit_cast(bf16x8_t, pw[0]);
+            pf[1] = __builtin_bit_cast(bf16x8_t, pw[1]);
+        };
+        // Software pipeline over the 40 chunks. Iteration j: [wait W1(j+1), W2(j); barrier] phase 2 of chunk j-1 with the
+        // LDS-DMA pieces of W1(j+2) and W2(j+1) behind its MFMAs (W1 stage j&1 held W1(j), read in iteration j-1; W2 stage
+        // (j+1)%3 held W2(j-2), read in iteration j-1: both free once every wave is past this barrier), then phase 1 of
+        // chunk j+1 interleaved with the GEGLU of chunk j. The pieces have all of that to land in.
+        typedef std::integral_constant<bool, true> yes_t;
+        typedef std::integral_constant<bool, false> no_t;
         __builtin_amdgcn_s_barrier();                    // every wave is done with the previous tile's LDS stages
         issue_w1(0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // W1(0) (and the X fragments)
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         issue_w1(1);
-        issue_w2(0);
-        f32x16_t a0v, a0g, a1v, a1g;
-        phase1(0, a0v, a0g);
-        auto body = [&](int j, f32x16_t& cv, f32x16_t& cg, f32x16_t& nv, f32x16_t& ng) __attribute__((always_inline)) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // W1(j+1), W2(j)
+        issue_w2(0, 0);
+        f32x16_t a0, a0g, a1, a1g;
+        bf16x8_t pf[2];
+        phase1(0, a0, a0g);
+        auto top = [&]() __attribute__((always_inline)) {
+            FF_STAMP(4);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
-            if (j + 2 < FNCH) issue_w1(j + 2);
-            if (j + 1 < FNCH) issue_w2(j + 1);
-            bf16x8_t pf[2];
-            // (Putting phase 1 and GEGLU into ONE basic block - unconditional phase 1, with or without a
-            // sched_group_barrier pattern of 1 MFMA : 1 LDS read : 11 VALU - made hipcc spill 55-64 registers; behind this
-            // branch it fits the 512 and still lets a third of the phase-1 MFMAs issue inside the GEGLU stream.)
-            if (j + 1 < FNCH) phase1(j + 1, nv, ng);
-            geglu(j, cv, cg, pf);
-            phase2(j, pf);
+            FF_STAMP(0);
         };
-        for (int j = 0; j < FNCH; j += 2) {
-            body(j, a0v, a0g, a1v, a1g);
-            body(j + 1, a1v, a1g, a0v, a0g);
+        top();                                           // iteration 0: no phase 2 yet
+        issue_w1(2);
+        issue_w2(1, 1);
+        phase1_geglu(0, a0, a0g, a1, a1g, pf);
+        FF_STAMP(2);
+        int st = 0;                                      // ring stage of W2(j - 1)
+        auto body = [&](int j, const f32x16_t& cv, const f32x16_t& cg, f32x16_t& nv, f32x16_t& ng, auto DW1, auto DW2)
+            __attribute__((always_inline)) {
+            top();
+            const int st2 = st + 2 >= W2_RING ? st + 2 - W2_RING : st + 2;
+            phase2(st, pf, DW1, DW2, j, st2);
+            st = st + 1 >= W2_RING ? 0 : st + 1;
+            FF_STAMP(3);
+            phase1_geglu(j, cv, cg, nv, ng, pf);
+            FF_STAMP(2);
+        };
+        for (int j = 1; j < FNCH - 3; j += 2) {          // j = 1 .. 36
+            body(j, a1, a1g, a0, a0g, yes_t(), yes_t());
+            body(j + 1, a0, a0g, a1, a1g, yes_t(), yes_t());
         }
+        body(FNCH - 3, a1, a1g, a0, a0g, yes_t(), yes_t());          // 37: W1(39), W2(38)
+        body(FNCH - 2, a0, a0g, a1, a1g, no_t(), yes_t());           // 38: W2(39) only
+        top();                                                       // 39: nothing left to overlap the last GEGLU with
+        phase2(st, pf, no_t(), no_t(), 0, 0);
+        st = st + 1 >= W2_RING ? 0 : st + 1;
+        geglu(FNCH - 1, a1, a1g, pf);
+        phase2(st, pf, no_t(), no_t(), 0, 0);
         // ---- epilogue: + b2, bf16, + residual; row-major through the wave-private patch (32 rows x 64 B per block)
         {
             int lane_e = lane;
@@ -365,9 +445,24 @@ void ff_geglu_fused320_kernel(const FfParams p) {
             }
         }
     }
+#ifdef DC_FF_STAMPS
+    if (blockIdx.x == 0 && tid == 0)
+        for (int i = 0; i < 5; ++i) atomicAdd(&g_ff_stamps[i], st_acc[i]);
+#endif
 }
 
 }  // namespace
+
+#ifdef DC_FF_STAMPS
+extern "C" int dc_ff_debug_stamps(unsigned long long* out, int reset) {
+    hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ff_stamps), sizeof(unsigned long long) * 8);
+    if (e == hipSuccess && reset) {
+        unsigned long long z[8] = {0};
+        e = hipMemcpyToSymbol(HIP_SYMBOL(g_ff_stamps), z, sizeof(z));
+    }
+    return (int)e;
+}
+#endif
 
 extern "C" int dc_ff_geglu_fused320(const uint16_t* x, int ldx, const float* ln_gamma, const float* ln_beta, float ln_eps,
                                     const uint16_t* w1, const float* b1, const uint16_t* w2p, const float* b2,
