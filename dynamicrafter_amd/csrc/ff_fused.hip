@@ -67,6 +67,56 @@ __device__ __forceinline__ void glds16f(const void* gsrc, unsigned lds_dst_unifo
         : "memory");
 }
 
+
+// LayerNorm of the rows held as X fragments (lanes (fr, 0) and (fr, 1) hold the two halves of row fr), two-pass in
+// registers (BasicTransformerBlock norm1/2/3, lvdm/modules/attention.py:225-227, eps 1e-5); the result is rounded to bf16
+// exactly where the stand-alone LayerNorm kernel rounds its output.
+__device__ __forceinline__ void ln_rows_inplace(bf16x8_t (&xf)[FD / 16], const float* ln_g, const float* ln_b, float eps, int fh) {
+    float sum = 0.f;
+#pragma unroll
+    for (int kk = 0; kk < FD / 16; ++kk) {
+        const u32x4_t w = __builtin_bit_cast(u32x4_t, xf[kk]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) sum += __uint_as_float(w[e] << 16) + __uint_as_float(w[e] & 0xffff0000u);
+    }
+    sum += __shfl_xor(sum, 32, 64);
+    const float mean = sum * (1.0f / FD);
+    // (opaque re-definitions between the passes: otherwise the 160 fp32 conversions of pass one are kept alive for passes
+    // two and three - 160 more registers than the kernels have)
+#pragma unroll
+    for (int kk = 0; kk < FD / 16; ++kk) asm volatile("" : "+v"(xf[kk]));
+    float q = 0.f;
+#pragma unroll
+    for (int kk = 0; kk < FD / 16; ++kk) {
+        const u32x4_t w = __builtin_bit_cast(u32x4_t, xf[kk]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float d0 = __uint_as_float(w[e] << 16) - mean, d1 = __uint_as_float(w[e] & 0xffff0000u) - mean;
+            q += d0 * d0 + d1 * d1;
+        }
+    }
+    q += __shfl_xor(q, 32, 64);
+    const float rstd = rsqrtf(q * (1.0f / FD) + eps);
+#pragma unroll
+    for (int kk = 0; kk < FD / 16; ++kk) asm volatile("" : "+v"(xf[kk]));
+#pragma unroll
+    for (int kk = 0; kk < FD / 16; ++kk) {
+        // gamma / beta in groups of 5 k steps (80 floats in flight): hoisted all at once they are 320 registers
+        if (kk % 5 == 0) asm volatile("" ::: "memory");
+        const u32x4_t w = __builtin_bit_cast(u32x4_t, xf[kk]);
+        const int c0 = kk * 16 + fh * 8;
+        const float4 g0 = *reinterpret_cast<const float4*>(ln_g + c0), g1 = *reinterpret_cast<const float4*>(ln_g + c0 + 4);
+        const float4 b0 = *reinterpret_cast<const float4*>(ln_b + c0), b1 = *reinterpret_cast<const float4*>(ln_b + c0 + 4);
+        u32x4_t o;
+        o[0] = pack_bf2((__uint_as_float(w[0] << 16) - mean) * rstd * g0.x + b0.x, (__uint_as_float(w[0] & 0xffff0000u) - mean) * rstd * g0.y + b0.y);
+        o[1] = pack_bf2((__uint_as_float(w[1] << 16) - mean) * rstd * g0.z + b0.z, (__uint_as_float(w[1] & 0xffff0000u) - mean) * rstd * g0.w + b0.w);
+        o[2] = pack_bf2((__uint_as_float(w[2] << 16) - mean) * rstd * g1.x + b1.x, (__uint_as_float(w[2] & 0xffff0000u) - mean) * rstd * g1.y + b1.y);
+        o[3] = pack_bf2((__uint_as_float(w[3] << 16) - mean) * rstd * g1.z + b1.z, (__uint_as_float(w[3] & 0xffff0000u) - mean) * rstd * g1.w + b1.w);
+        xf[kk] = __builtin_bit_cast(bf16x8_t, o);
+        asm volatile("" : "+v"(xf[kk]));          // ... and the arithmetic of a group is done before the next group loads
+    }
+}
+
 struct FfParams {
     const bf16_t* X; int ldx;
     const bf16_t* W1;            // [>= 2560][320]: rows 0..1279 value, 1280..2559 gate (torch ff.net.0.proj.weight order)
@@ -159,45 +209,7 @@ void ff_geglu_fused320_kernel(const FfParams p) {
             const bf16_t* xr = p.X + (size_t)mr * p.ldx + fh * 8;
 #pragma unroll
             for (int kk = 0; kk < FD / 16; ++kk) xf[kk] = *reinterpret_cast<const bf16x8_t*>(xr + kk * 16);
-            if constexpr (LN) {
-                // LayerNorm over the row (attention.py:225-227 norm3, eps 1e-5), two-pass in registers: lanes (fr, 0) and
-                // (fr, 1) hold the two halves of row fr; the result is rounded to bf16 exactly where the stand-alone
-                // LayerNorm kernel rounds its output.
-                float sum = 0.f;
-#pragma unroll
-                for (int kk = 0; kk < FD / 16; ++kk) {
-                    const u32x4_t w = __builtin_bit_cast(u32x4_t, xf[kk]);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) sum += __uint_as_float(w[e] << 16) + __uint_as_float(w[e] & 0xffff0000u);
-                }
-                sum += __shfl_xor(sum, 32, 64);
-                const float mean = sum * (1.0f / FD);
-                float q = 0.f;
-#pragma unroll
-                for (int kk = 0; kk < FD / 16; ++kk) {
-                    const u32x4_t w = __builtin_bit_cast(u32x4_t, xf[kk]);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const float d0 = __uint_as_float(w[e] << 16) - mean, d1 = __uint_as_float(w[e] & 0xffff0000u) - mean;
-                        q += d0 * d0 + d1 * d1;
-                    }
-                }
-                q += __shfl_xor(q, 32, 64);
-                const float rstd = rsqrtf(q * (1.0f / FD) + p.ln_eps);
-#pragma unroll
-                for (int kk = 0; kk < FD / 16; ++kk) {
-                    const u32x4_t w = __builtin_bit_cast(u32x4_t, xf[kk]);
-                    const int c0 = kk * 16 + fh * 8;
-                    const float4 g0 = *reinterpret_cast<const float4*>(p.ln_g + c0), g1 = *reinterpret_cast<const float4*>(p.ln_g + c0 + 4);
-                    const float4 b0 = *reinterpret_cast<const float4*>(p.ln_b + c0), b1 = *reinterpret_cast<const float4*>(p.ln_b + c0 + 4);
-                    u32x4_t o;
-                    o[0] = pack_bf2((__uint_as_float(w[0] << 16) - mean) * rstd * g0.x + b0.x, (__uint_as_float(w[0] & 0xffff0000u) - mean) * rstd * g0.y + b0.y);
-                    o[1] = pack_bf2((__uint_as_float(w[1] << 16) - mean) * rstd * g0.z + b0.z, (__uint_as_float(w[1] & 0xffff0000u) - mean) * rstd * g0.w + b0.w);
-                    o[2] = pack_bf2((__uint_as_float(w[2] << 16) - mean) * rstd * g1.x + b1.x, (__uint_as_float(w[2] & 0xffff0000u) - mean) * rstd * g1.y + b1.y);
-                    o[3] = pack_bf2((__uint_as_float(w[3] << 16) - mean) * rstd * g1.z + b1.z, (__uint_as_float(w[3] & 0xffff0000u) - mean) * rstd * g1.w + b1.w);
-                    xf[kk] = __builtin_bit_cast(bf16x8_t, o);
-                }
-            }
+            if constexpr (LN) ln_rows_inplace(xf, p.ln_g, p.ln_b, p.ln_eps, fh);
         }
         f32x16_t acc[FD / 32];
 #pragma unroll
@@ -451,6 +463,143 @@ void ff_geglu_fused320_kernel(const FfParams p) {
 #endif
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// LayerNorm + Linear for dim = 320 (level-0 transformers): out[M, N] = LayerNorm(x) W^T (+ bias), N a multiple of 32.
+//   reference: norm1 -> attn1.to_q/k/v, norm2 -> attn2.to_q (and the temporal blocks' two self-attentions),
+//   BasicTransformerBlock._forward lvdm/modules/attention.py:242-245 with CrossAttention.forward :101-105
+// As LayerNorm kernel + GEMM the normalised copy is written and read back (2 x 189 MB per use at the 1024 config) and the
+// GEMM's 256 x 320 tiles read every activation row N / 320 times. Here a workgroup owns 128 rows for the whole N: the
+// (normalised) X fragments of a wave's 32 rows stay in registers as in the FeedForward kernel above, the weight streams
+// through a two-deep LDS ring in chunks of 32 output channels (20 KB, 20 MFMAs per wave), each chunk's 32 x 32 block is
+// stored row-major through a wave-private LDS patch. 50 KB of LDS and 153 registers: three workgroups per CU, i.e. three
+// waves per SIMD that are never in step, which hides the X loads at the head of a tile and the stores of the epilogue.
+// The kernel is bound by the HBM writes of `out` (N / 320 x 189 MB), not by the matrix pipe.
+constexpr int LCH = 32;                        // output channels per chunk
+constexpr int LW_STAGE = LCH * FD * 2;         // 20 KB: 5 K tiles of [32 rows][128 B]
+constexpr int LL_LDS = 2 * LW_STAGE + 4 * 2048 + 2 * FD * 4;      // ring + epilogue patches + LayerNorm gamma / beta
+
+struct LlParams {
+    const bf16_t* X; int ldx;
+    const bf16_t* W;             // [>= N][320]
+    const float* bias;           // [N] or nullptr
+    bf16_t* O; int ldo;
+    int M, N;
+    const float* ln_g; const float* ln_b; float ln_eps;
+};
+
+template <bool LN>
+__global__ __launch_bounds__(256, 3)
+void ln_linear320_kernel(const LlParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fr = lane & 31, fh = lane >> 5;
+    const unsigned lds_base = (unsigned)(unsigned long)((lds_char_t*)smem);
+    char* const ebuf = smem + 2 * LW_STAGE + wave * 2048;
+    const int m0 = blockIdx.x * FBM + wave * 32;
+    const bool full_tile = (int)blockIdx.x * FBM + FBM <= p.M;         // ragged last tile: uncounted vmcnt waits
+    const int nch = p.N / LCH;
+
+    // LDS-DMA of chunk c: 32 weight rows x 640 B = 20 pieces of 8 rows x 128 B, 5 per wave
+    unsigned vo[5];
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+        const int u = wave * 5 + i;                      // (K tile t, 8-row group g): LDS offset u * 1024
+        const int t = u >> 2, g = u & 3;
+        vo[i] = (unsigned)((g * 8 + (lane >> 3)) * (FD * 2) + t * 128 + (((lane & 7) ^ ((g * 4 + (lane >> 4)) & 7)) << 4));
+        asm volatile("" : "+v"(vo[i]));
+    }
+    auto dma_piece = [&](unsigned lds_dst, unsigned voff, uint64_t sbase) __attribute__((always_inline)) {
+        unsigned keep;
+        asm volatile(
+            "s_mov_b32 %0, m0\n\t"
+            "s_mov_b32 m0, %1\n\t"
+            "s_nop 0\n\t"
+            "global_load_lds_dwordx4 %2, %3\n\t"
+            "s_mov_b32 m0, %0"
+            : "=&s"(keep)
+            : "s"(lds_dst), "v"(voff), "s"(sbase)
+            : "memory");
+    };
+    auto w_base = [&](int c) { return (uint64_t)(uintptr_t)p.W + (uint64_t)c * (LCH * FD * 2); };
+    auto w_dst = [&](int c, int i) { return lds_base + (c & 1) * LW_STAGE + (wave * 5 + i) * 1024; };
+
+#pragma unroll
+    for (int i = 0; i < 5; ++i) dma_piece(w_dst(0, i), vo[i], w_base(0));
+
+    // ---- X fragments of this wave's 32 rows (B operand: lane (row fr, half fh) holds k = 16 kk + 8 fh .. + 7)
+    bf16x8_t xf[FD / 16];
+    float* const lns = reinterpret_cast<float*>(smem + 2 * LW_STAGE + 4 * 2048);
+    {
+        int mr = m0 + fr;
+        if (mr >= p.M) mr = p.M - 1;
+        const bf16_t* xr = p.X + (size_t)mr * p.ldx + fh * 8;
+#pragma unroll
+        for (int kk = 0; kk < FD / 16; ++kk) xf[kk] = *reinterpret_cast<const bf16x8_t*>(xr + kk * 16);
+        if constexpr (LN) {
+            for (int i = tid; i < FD; i += 256) { lns[i] = p.ln_g[i]; lns[FD + i] = p.ln_b[i]; }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");     // X, gamma / beta and W(0): the compiler's own vmcnt
+    __builtin_amdgcn_s_barrier();                                   // accounting does not see the asm LDS-DMA, so the
+    asm volatile("" ::: "memory");                                  // loads are waited for explicitly
+    if constexpr (LN) ln_rows_inplace(xf, lns, lns + FD, p.ln_eps, fh);
+
+    constexpr int PD = 6;
+    for (int c = 0; c < nch; ++c) {
+        if (c > 0) {
+            // W(c) was issued during chunk c-1, in front of that chunk's two stores
+            if (full_tile) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+        }
+        const char* s1 = smem + (c & 1) * LW_STAGE;
+        f32x16_t acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        bf16x8_t wr[PD];
+        auto rd = [&](int kk, int slot) __attribute__((always_inline)) {
+            wr[slot] = *(lds_vfrag_t*)((lds_char_t*)s1 + (kk >> 2) * 4096 + off128(fr, (kk & 3) * 2 + fh));
+        };
+#pragma unroll
+        for (int kk = 0; kk < PD; ++kk) rd(kk, kk);
+        const bool more = c + 1 < nch;
+        const uint64_t nb = w_base(c + 1);
+#pragma unroll
+        for (int kk = 0; kk < FD / 16; ++kk) {
+            bf16x8_t f = wr[kk % PD];
+            if (kk + PD < FD / 16) rd(kk + PD, kk % PD);
+            asm volatile("" : "+v"(f));
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f, xf[kk], acc, 0, 0, 0);
+            if (kk < 5 && more) dma_piece(w_dst(c + 1, kk), vo[kk], nb);
+        }
+        // ---- chunk epilogue: + bias, bf16, row-major 16-byte stores through the wave-private patch (32 rows x 64 B)
+        {
+            const int n0 = c * LCH;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float4 bv = {0.f, 0.f, 0.f, 0.f};
+                if (p.bias) bv = *reinterpret_cast<const float4*>(p.bias + n0 + 8 * q + 4 * fh);
+                uint2 pk;
+                pk.x = pack_bf2(acc[4 * q] + bv.x, acc[4 * q + 1] + bv.y);
+                pk.y = pack_bf2(acc[4 * q + 2] + bv.z, acc[4 * q + 3] + bv.w);
+                *reinterpret_cast<uint2*>(ebuf + fr * 64 + (((2 * q + fh) ^ (((fr >> 1) & 3) << 1)) << 3)) = pk;
+            }
+            const int rrow = lane >> 2, rc = lane & 3;
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int r = t * 16 + rrow;
+                const u32x4_t d = *reinterpret_cast<const u32x4_t*>(ebuf + r * 64 + ((rc ^ ((r >> 1) & 3)) << 4));
+                const int m = m0 + r;
+                if (m < p.M) *reinterpret_cast<u32x4_t*>(p.O + (size_t)m * p.ldo + n0 + rc * 8) = d;
+            }
+        }
+    }
+}
+
 }  // namespace
 
 #ifdef DC_FF_STAMPS
@@ -487,6 +636,31 @@ extern "C" int dc_ff_geglu_fused320(const uint16_t* x, int ldx, const float* ln_
     const dim3 grid(tiles < 256 ? tiles : 256);
     if (ln_gamma) hipLaunchKernelGGL(ff_geglu_fused320_kernel<true>, grid, dim3(256), FF_LDS, (hipStream_t)stream_, p);
     else hipLaunchKernelGGL(ff_geglu_fused320_kernel<false>, grid, dim3(256), FF_LDS, (hipStream_t)stream_, p);
+    DC_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int dc_ln_linear320(const uint16_t* x, int ldx, const float* ln_gamma, const float* ln_beta, float ln_eps,
+                               const uint16_t* w, const float* bias, uint16_t* out, int ldo, int M, int N, void* stream_) {
+    if (!x || !w || !out || ((ln_gamma == nullptr) != (ln_beta == nullptr))) return DC_ERR_ARG;
+    if (M < 1 || N < LCH || N % LCH || ldx % 8 || ldo % 8) return DC_ERR_SHAPE;
+    if (((uintptr_t)x | (uintptr_t)out | (uintptr_t)w) % 16) return DC_ERR_SHAPE;
+    static bool configured = false;
+    if (!configured) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ln_linear320_kernel<false>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, LL_LDS);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ln_linear320_kernel<true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, LL_LDS);
+        if (e != hipSuccess) return (int)e;
+        configured = true;
+    }
+    LlParams p;
+    p.X = x; p.ldx = ldx; p.W = w; p.bias = bias; p.O = out; p.ldo = ldo; p.M = M; p.N = N;
+    p.ln_g = ln_gamma; p.ln_b = ln_beta; p.ln_eps = ln_eps;
+    const dim3 grid((M + FBM - 1) / FBM);
+    if (ln_gamma) hipLaunchKernelGGL(ln_linear320_kernel<true>, grid, dim3(256), LL_LDS, (hipStream_t)stream_, p);
+    else hipLaunchKernelGGL(ln_linear320_kernel<false>, grid, dim3(256), LL_LDS, (hipStream_t)stream_, p);
     DC_CHECK_LAUNCH();
     return 0;
 }

@@ -26,6 +26,7 @@ import os
 
 _BF16 = torch.bfloat16
 _FF_FUSED = os.environ.get("DC_FF_FUSED", "1") != "0"
+_LN_FUSED = os.environ.get("DC_LN_FUSED", "1") != "0"      # A/B switches of the dim-320 fused kernels (ff_fused.hip)
 C_IN_PAD = 64   # conv_in consumes the 8 latent+concat channels zero-padded to one 64-wide K slice
 
 
@@ -390,19 +391,26 @@ class UNetModel(nn.Module):
             r = ops.gemm(n, cw, dst, tconv=tc, residual=h2 if last else None)
         return r
 
-    def _attn_self_spatial(self, Wa, n, h, g, heads):
+    def _ln_linear(self, h, ln, pw, out):
+        """Linear(LayerNorm(h)): at dim 320 and level-0 row counts one kernel with the LayerNorm in registers (the
+        normalised copy never reaches HBM), otherwise LayerNorm kernel + GEMM."""
+        if _LN_FUSED and pw.K == 320 and pw.N % 32 == 0 and h.shape[0] >= 32768:
+            return ops.ln_linear320(h, pw, out, ln=ln, ln_eps=1e-5)
+        return ops.gemm(self._ln(h, ln, "ln"), pw, out)
+
+    def _attn_self_spatial(self, Wa, ln, h, g, heads):
         A = self._arena
-        M, dev, Cc = n.shape[0], n.device, heads * 64
-        qkv = ops.gemm(n, Wa["qkv"], A.get("qkv", M, 3 * Cc, device=dev))
+        M, dev, Cc = h.shape[0], h.device, heads * 64
+        qkv = self._ln_linear(h, ln, Wa["qkv"], A.get("qkv", M, 3 * Cc, device=dev))
         att = A.get("att", M, Cc, device=dev)
         ops.flash_attn(qkv[:, :Cc], qkv[:, Cc:2 * Cc], qkv[:, 2 * Cc:], att, batch=g["F"], heads=heads, Lq=g["HW"],
                        Lk=g["HW"], scale=0.125)
         return ops.gemm(att, Wa["out"], h, residual=h)
 
-    def _attn_self_temporal(self, Wa, n, h, g, heads):
+    def _attn_self_temporal(self, Wa, ln, h, g, heads):
         A = self._arena
-        M, dev, Cc = n.shape[0], n.device, heads * 64
-        qkv = ops.gemm(n, Wa["qkv"], A.get("qkv", M, 3 * Cc, device=dev))
+        M, dev, Cc = h.shape[0], h.device, heads * 64
+        qkv = self._ln_linear(h, ln, Wa["qkv"], A.get("qkv", M, 3 * Cc, device=dev))
         att = A.get("att", M, Cc, device=dev)
         ops.temporal_attn(qkv, att, B=g["B"], T=g["T"], HW=g["HW"], heads=heads, scale=0.125)
         return ops.gemm(att, Wa["out"], h, residual=h)
@@ -425,7 +433,7 @@ class UNetModel(nn.Module):
         n = self._gn(x, W["norm"], "gn", n_inst=g["F"], rpi=g["HW"], eps=1e-6, silu=False)
         h = ops.gemm(n, W["proj_in"], A.get("tr_h", M, Cc, device=dev))
         B_ = W["blk"]
-        return self._attn_self_spatial(B_["attn1"], self._ln(h, B_["norm1"], "ln"), h, g, heads)
+        return self._attn_self_spatial(B_["attn1"], B_["norm1"], h, g, heads)
 
     def _context_kv(self, B_, ctx, tag):
         """k/v (text) and k_ip/v_ip (image) projections of the per-frame context rows: one GEMM [F*Lc, 4C] (attention.py
@@ -450,8 +458,7 @@ class UNetModel(nn.Module):
         A = self._arena
         M, dev, Cc = x.shape[0], x.device, x.shape[1]
         B_ = W["blk"]
-        n = self._ln(h, B_["norm2"], "ln")
-        q = ops.gemm(n, B_["q2"], A.get("q2", M, Cc, device=dev))
+        q = self._ln_linear(h, B_["norm2"], B_["q2"], A.get("q2", M, Cc, device=dev))
         kv = None if g.get("ctx_kv") is None else g["ctx_kv"].get(id(B_))
         if kv is None:
             kv = self._context_kv(B_, g["ctx"], "kvctx")       # rows [F * Lc, 4C], Lc = n_text + L_img
@@ -478,8 +485,8 @@ class UNetModel(nn.Module):
         n = self._gn(x, W["norm"], "gn", n_inst=g["B"], rpi=g["T"] * g["HW"], eps=1e-6, silu=False)
         h = ops.gemm(n, W["proj_in"], A.get("tr_h", M, inner, device=dev))
         B_ = W["blk"]
-        h = self._attn_self_temporal(B_["attn1"], self._ln(h, B_["norm1"], "ln"), h, g, heads)
-        h = self._attn_self_temporal(B_["attn2"], self._ln(h, B_["norm2"], "ln"), h, g, heads)
+        h = self._attn_self_temporal(B_["attn1"], B_["norm1"], h, g, heads)
+        h = self._attn_self_temporal(B_["attn2"], B_["norm2"], h, g, heads)
         h = self._ff(B_, h)
         return ops.gemm(h, W["proj_out"], out if out is not None else A.get(out_tag, M, Cc, device=dev), residual=x)
 

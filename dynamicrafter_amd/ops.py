@@ -422,6 +422,22 @@ def ff_geglu_fused320(x, pw1, w2p, b2, out, residual=None, ln=None, ln_eps=1e-5)
     return out
 
 
+def ln_linear320(x, pw, out, ln=None, ln_eps=1e-5):
+    """out = Linear(LayerNorm(x) if ln else x) for dim 320 in one launch; pw = PackedWeight.linear (K = 320, N % 32 == 0);
+    ln = (gamma, beta) fp32 or None."""
+    _rows(x, "x"); _rows(out, "out")
+    M = x.shape[0]
+    if pw.K != 320 or pw.N % 32:
+        raise ValueError("ln_linear320: K must be 320 and N a multiple of 32")
+    _need_rows(x, M, 320, "x"); _need_rows(out, M, pw.N, "out")
+    if ln is not None:
+        _need(ln[0], 320, "ln gamma"); _need(ln[1], 320, "ln beta")
+    _launch("ln_linear320", 2.0 * M * pw.N * 320, 2.0 * M * (320 + pw.N) + 2.0 * pw.N * 320, _hip.lib().dc_ln_linear320,
+            _ptr(x), x.stride(0), _ptr(None if ln is None else ln[0]), _ptr(None if ln is None else ln[1]), ln_eps, _ptr(pw.w),
+            _ptr(pw.bias), _ptr(out), out.stride(0), M, pw.N, stream_ptr())
+    return out
+
+
 def attn_small(q, k, v, o, *, batch, heads, Lq, Lk, d, scale, causal=False):
     """Any-head-width attention (CLIP towers): q/o rows [batch*Lq, >= heads*d], k/v rows [batch*Lk, >= heads*d]."""
     for t, n in ((q, "q"), (k, "k"), (v, "v"), (o, "o")):

@@ -196,6 +196,14 @@ int dc_ff_geglu_fused320(const uint16_t* x, int ldx, const float* ln_gamma, cons
                          const uint16_t* w1, const float* b1, const uint16_t* w2p, const float* b2, const uint16_t* residual,
                          int ldr, uint16_t* out, int ldo, int M, void* stream);
 
+/* LayerNorm + Linear for dim = 320: out[M,N] = n W^T (+ bias), n = x, or LayerNorm(x; ln_gamma, ln_beta, ln_eps) when
+ * ln_gamma != NULL (rounded to bf16 like dc_layernorm's output); N % 32 == 0. x/out: bf16 rows (ld % 8 == 0, 16-byte
+ * aligned); w: bf16 [>= N][320] as dc_gemm_conv takes a Linear weight; bias fp32 [N] or NULL.
+ * replaces norm1 -> attn1.to_q/k/v (one [960, 320] weight) and norm2 -> attn2.to_q of BasicTransformerBlock._forward
+ * lvdm/modules/attention.py:242-245 (CrossAttention.forward :101-105) at the UNet's level 0 */
+int dc_ln_linear320(const uint16_t* x, int ldx, const float* ln_gamma, const float* ln_beta, float ln_eps, const uint16_t* w,
+                    const float* bias, uint16_t* out, int ldo, int M, int N, void* stream);
+
 /* ---- conditioning encoders (once per clip) ---------------------------------------------------- */
 
 /* Multi-head attention for any (even) head width d <= 256 and Lk <= 1024, optional causal mask (key j visible to query

@@ -643,6 +643,33 @@ def test_cross_attn_dual_vs_torch(ops, B, heads, Lq, nt, ni, s2):
     assert rel_l2(o, o2) < 6e-3
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,N", [(128, 320), (40000, 960), (333, 64)])
+def test_ln_linear320_vs_layernorm_plus_gemm(ops, M, N):
+    """dc_ln_linear320 = dc_layernorm + dc_gemm_conv (same rounding points) and = torch fp32 LayerNorm + Linear"""
+    g = torch.Generator().manual_seed(M + N)
+    x = (torch.randn(M, 320, generator=g) * 1.3 + 0.4).to(torch.bfloat16)
+    w = torch.randn(N, 320, generator=g) * 320 ** -0.5
+    b = torch.randn(N, generator=g) * 0.1
+    gam = 1 + 0.2 * torch.randn(320, generator=g); bet = 0.3 * torch.randn(320, generator=g)
+    for bias in (None, b):
+        pw = ops.PackedWeight.linear(w, bias, DEV)
+        xd = x.to(DEV)
+        out = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+        ops.ln_linear320(xd, pw, out, ln=(gam.to(DEV), bet.to(DEV)))
+        n = torch.empty_like(xd)
+        ops.layernorm(xd, n, gam.to(DEV), bet.to(DEV), 1e-5)
+        want = torch.empty_like(out)
+        ops.gemm(n, pw, want)
+        assert rel_l2(out, want) < 2e-3
+        ref = torch.nn.functional.linear(torch.nn.functional.layer_norm(x.float(), (320,), gam, bet, 1e-5), w, bias)
+        assert rel_l2(out.float().cpu(), ref) < 6e-3
+        # without the LayerNorm it is the plain Linear
+        ops.ln_linear320(xd, pw, out)
+        ops.gemm(xd, pw, want)
+        assert rel_l2(out, want) < 1e-3
+
+
 @pytest.mark.parametrize("M", [128 * 5, 1000, 40000])
 def test_ff_geglu_fused320_vs_torch(ops, M):
     """ff1 -> GEGLU -> ff2 (+ residual) in one kernel (dim 320) vs fp32 torch and vs the two-GEMM path."""

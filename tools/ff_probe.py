@@ -29,3 +29,19 @@ for name, fn in (("pair", pair), ("fused", fused), ("ln+pair", ln_pair), ("lnfus
     e1.record(); torch.cuda.synchronize()
     us = e0.elapsed_time(e1) / 10 * 1e3
     print(f"{name:8s} M={M}: {us:8.1f} us  {2.0 * M * 3840 * 320 / us / 1e6:7.1f} TF/s", flush=True)
+
+# LayerNorm + Linear (dc_ln_linear320) vs LayerNorm kernel + GEMM
+for N in (960, 320):
+    pw = ops.PackedWeight.linear(torch.randn(N, 320, generator=g) * 320 ** -0.5, None, DEV)
+    o = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+    def two(): ops.layernorm(h, x, gam, bet, 1e-5); ops.gemm(x, pw, o)
+    def one(): ops.ln_linear320(h, pw, o, ln=(gam, bet))
+    for name, fn in (("ln+gemm", two), ("ln_linear", one), ("ln+gemm", two), ("ln_linear", one)):
+        for _ in range(2): fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10): fn()
+        e1.record(); torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) / 10 * 1e3
+        print(f"{name:10s} M={M} N={N}: {us:8.1f} us  {2.0 * M * N * 320 / us / 1e6:7.1f} TF/s  {2.0 * M * (320 + N) / us / 1e6:6.2f} TB/s", flush=True)
