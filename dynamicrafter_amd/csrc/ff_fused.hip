@@ -117,6 +117,26 @@ __device__ __forceinline__ void ln_rows_inplace(bf16x8_t (&xf)[FD / 16], const f
     }
 }
 
+// x * a[c] + b[c] on the rows held as X fragments (GroupNorm with the statistics already known: a = gamma rstd,
+// b = beta - mean a, the arithmetic of gn_apply_kernel in norms.hip), rounded to bf16 like that kernel's output
+__device__ __forceinline__ void affine_rows_inplace(bf16x8_t (&xf)[FD / 16], const float* a, const float* b, int fh) {
+#pragma unroll
+    for (int kk = 0; kk < FD / 16; ++kk) {
+        if (kk % 5 == 0) asm volatile("" ::: "memory");
+        const u32x4_t w = __builtin_bit_cast(u32x4_t, xf[kk]);
+        const int c0 = kk * 16 + fh * 8;
+        const float4 g0 = *reinterpret_cast<const float4*>(a + c0), g1 = *reinterpret_cast<const float4*>(a + c0 + 4);
+        const float4 b0 = *reinterpret_cast<const float4*>(b + c0), b1 = *reinterpret_cast<const float4*>(b + c0 + 4);
+        u32x4_t o;
+        o[0] = pack_bf2(__uint_as_float(w[0] << 16) * g0.x + b0.x, __uint_as_float(w[0] & 0xffff0000u) * g0.y + b0.y);
+        o[1] = pack_bf2(__uint_as_float(w[1] << 16) * g0.z + b0.z, __uint_as_float(w[1] & 0xffff0000u) * g0.w + b0.w);
+        o[2] = pack_bf2(__uint_as_float(w[2] << 16) * g1.x + b1.x, __uint_as_float(w[2] & 0xffff0000u) * g1.y + b1.y);
+        o[3] = pack_bf2(__uint_as_float(w[3] << 16) * g1.z + b1.z, __uint_as_float(w[3] & 0xffff0000u) * g1.w + b1.w);
+        xf[kk] = __builtin_bit_cast(bf16x8_t, o);
+        asm volatile("" : "+v"(xf[kk]));
+    }
+}
+
 struct FfParams {
     const bf16_t* X; int ldx;
     const bf16_t* W1;            // [>= 2560][320]: rows 0..1279 value, 1280..2559 gate (torch ff.net.0.proj.weight order)
@@ -485,10 +505,12 @@ struct LlParams {
     const float* bias;           // [N] or nullptr
     bf16_t* O; int ldo;
     int M, N;
-    const float* ln_g; const float* ln_b; float ln_eps;
+    const float* ln_g; const float* ln_b; float ln_eps;      // LayerNorm / GroupNorm gamma, beta
+    const float2* gn_stats; int gn_groups, gn_rpi;           // NORM 2: (mean, rstd) [inst][group], rows per instance (% 128 == 0)
 };
 
-template <bool LN>
+// NORM 0: none, 1: LayerNorm over the row, 2: GroupNorm with known statistics (a per-instance affine map)
+template <int NORM>
 __global__ __launch_bounds__(256, 3)
 void ln_linear320_kernel(const LlParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -538,14 +560,22 @@ void ln_linear320_kernel(const LlParams p) {
         const bf16_t* xr = p.X + (size_t)mr * p.ldx + fh * 8;
 #pragma unroll
         for (int kk = 0; kk < FD / 16; ++kk) xf[kk] = *reinterpret_cast<const bf16x8_t*>(xr + kk * 16);
-        if constexpr (LN) {
+        if constexpr (NORM == 1) {
             for (int i = tid; i < FD; i += 256) { lns[i] = p.ln_g[i]; lns[FD + i] = p.ln_b[i]; }
+        } else if constexpr (NORM == 2) {
+            const int inst = (int)(((long long)blockIdx.x * FBM) / p.gn_rpi);      // a tile never straddles two instances
+            for (int i = tid; i < FD; i += 256) {
+                const float2 st = p.gn_stats[(size_t)inst * p.gn_groups + i / (FD / p.gn_groups)];
+                const float a = p.ln_g[i] * st.y;
+                lns[i] = a; lns[FD + i] = p.ln_b[i] - st.x * a;
+            }
         }
     }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");     // X, gamma / beta and W(0): the compiler's own vmcnt
     __builtin_amdgcn_s_barrier();                                   // accounting does not see the asm LDS-DMA, so the
     asm volatile("" ::: "memory");                                  // loads are waited for explicitly
-    if constexpr (LN) ln_rows_inplace(xf, lns, lns + FD, p.ln_eps, fh);
+    if constexpr (NORM == 1) ln_rows_inplace(xf, lns, lns + FD, p.ln_eps, fh);
+    if constexpr (NORM == 2) affine_rows_inplace(xf, lns, lns + FD, fh);
 
     constexpr int PD = 6;
     for (int c = 0; c < nch; ++c) {
@@ -640,27 +670,49 @@ extern "C" int dc_ff_geglu_fused320(const uint16_t* x, int ldx, const float* ln_
     return 0;
 }
 
+static int launch_norm_linear320(int norm, const LlParams& p, hipStream_t stream) {
+    static bool configured = false;
+    if (!configured) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ln_linear320_kernel<0>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, LL_LDS);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ln_linear320_kernel<1>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, LL_LDS);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ln_linear320_kernel<2>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, LL_LDS);
+        if (e != hipSuccess) return (int)e;
+        configured = true;
+    }
+    const dim3 grid((p.M + FBM - 1) / FBM);
+    if (norm == 1) hipLaunchKernelGGL(ln_linear320_kernel<1>, grid, dim3(256), LL_LDS, stream, p);
+    else if (norm == 2) hipLaunchKernelGGL(ln_linear320_kernel<2>, grid, dim3(256), LL_LDS, stream, p);
+    else hipLaunchKernelGGL(ln_linear320_kernel<0>, grid, dim3(256), LL_LDS, stream, p);
+    DC_CHECK_LAUNCH();
+    return 0;
+}
+
 extern "C" int dc_ln_linear320(const uint16_t* x, int ldx, const float* ln_gamma, const float* ln_beta, float ln_eps,
                                const uint16_t* w, const float* bias, uint16_t* out, int ldo, int M, int N, void* stream_) {
     if (!x || !w || !out || ((ln_gamma == nullptr) != (ln_beta == nullptr))) return DC_ERR_ARG;
     if (M < 1 || N < LCH || N % LCH || ldx % 8 || ldo % 8) return DC_ERR_SHAPE;
     if (((uintptr_t)x | (uintptr_t)out | (uintptr_t)w) % 16) return DC_ERR_SHAPE;
-    static bool configured = false;
-    if (!configured) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ln_linear320_kernel<false>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, LL_LDS);
-        if (e == hipSuccess)
-            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ln_linear320_kernel<true>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, LL_LDS);
-        if (e != hipSuccess) return (int)e;
-        configured = true;
-    }
     LlParams p;
     p.X = x; p.ldx = ldx; p.W = w; p.bias = bias; p.O = out; p.ldo = ldo; p.M = M; p.N = N;
-    p.ln_g = ln_gamma; p.ln_b = ln_beta; p.ln_eps = ln_eps;
-    const dim3 grid((M + FBM - 1) / FBM);
-    if (ln_gamma) hipLaunchKernelGGL(ln_linear320_kernel<true>, grid, dim3(256), LL_LDS, (hipStream_t)stream_, p);
-    else hipLaunchKernelGGL(ln_linear320_kernel<false>, grid, dim3(256), LL_LDS, (hipStream_t)stream_, p);
-    DC_CHECK_LAUNCH();
-    return 0;
+    p.ln_g = ln_gamma; p.ln_b = ln_beta; p.ln_eps = ln_eps; p.gn_stats = nullptr; p.gn_groups = 1; p.gn_rpi = FBM;
+    return launch_norm_linear320(ln_gamma ? 1 : 0, p, (hipStream_t)stream_);
+}
+
+extern "C" int dc_gn_linear320(const uint16_t* x, int ldx, const float* gamma, const float* beta, const float* stats,
+                               int groups, int rows_per_inst, const uint16_t* w, const float* bias, uint16_t* out, int ldo,
+                               int M, int N, void* stream_) {
+    if (!x || !w || !out || !gamma || !beta || !stats) return DC_ERR_ARG;
+    if (M < 1 || N < LCH || N % LCH || ldx % 8 || ldo % 8) return DC_ERR_SHAPE;
+    if (groups < 1 || FD % groups || rows_per_inst < FBM || rows_per_inst % FBM || M % rows_per_inst) return DC_ERR_SHAPE;
+    if (((uintptr_t)x | (uintptr_t)out | (uintptr_t)w) % 16) return DC_ERR_SHAPE;
+    LlParams p;
+    p.X = x; p.ldx = ldx; p.W = w; p.bias = bias; p.O = out; p.ldo = ldo; p.M = M; p.N = N;
+    p.ln_g = gamma; p.ln_b = beta; p.ln_eps = 0.f;
+    p.gn_stats = reinterpret_cast<const float2*>(stats); p.gn_groups = groups; p.gn_rpi = rows_per_inst;
+    return launch_norm_linear320(2, p, (hipStream_t)stream_);
 }

@@ -289,6 +289,32 @@ extern "C" int dc_groupnorm(const uint16_t* x, int ldx, uint16_t* y, int ldy, co
     return 0;
 }
 
+// statistics only: (mean, rstd) per (instance, group) -> stats_out [n_inst][groups][2] fp32, for consumers that apply the
+// normalisation themselves (dc_gn_linear320 folds it into the Linear that follows)
+extern "C" int dc_groupnorm_stats(const uint16_t* x, int ldx, int C, int groups, int n_inst, int rows_per_inst, float eps,
+                                  float* workspace, float* stats_out, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!x || !workspace || !stats_out) return DC_ERR_ARG;
+    if (C % 8 != 0 || groups <= 0 || groups > 64 || C % groups != 0 || ldx % 8 != 0) return DC_ERR_SHAPE;
+    if (n_inst <= 0 || rows_per_inst <= 0) return DC_ERR_SHAPE;
+    const int vecs = C / 8;
+    if (vecs > 1024) return DC_ERR_SHAPE;
+    int rpp = 256 / vecs;
+    if (rpp < 1) rpp = 1;
+    const int threads = vecs * rpp;
+    const GnGeom g = gn_geom(n_inst, rows_per_inst);
+    float2* partial = reinterpret_cast<float2*>(workspace);
+    const size_t lds = (size_t)2 * rpp * C * sizeof(float);
+    if (lds > 64 * 1024) return DC_ERR_SHAPE;
+    hipLaunchKernelGGL(gn_partial_kernel, dim3(g.chunks, n_inst), dim3(threads), lds, stream, x, ldx, C, groups,
+                       rows_per_inst, g.rows_per_chunk, g.chunks, vecs, rpp, partial);
+    DC_CHECK_LAUNCH();
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(groups, n_inst), dim3(64), 0, stream, partial, g.chunks, groups, rows_per_inst,
+                       g.rows_per_chunk, C / groups, eps, reinterpret_cast<float2*>(stats_out));
+    DC_CHECK_LAUNCH();
+    return 0;
+}
+
 extern "C" int dc_layernorm(const uint16_t* x, int ldx, uint16_t* y, int ldy, const float* gamma, const float* beta,
                             int rows, int C, float eps, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;

@@ -398,6 +398,15 @@ class UNetModel(nn.Module):
             return ops.ln_linear320(h, pw, out, ln=ln, ln_eps=1e-5)
         return ops.gemm(self._ln(h, ln, "ln"), pw, out)
 
+    def _gn_linear(self, x, gnw, pw, out, *, n_inst, rpi):
+        """Linear(GroupNorm(x)) (eps 1e-6, no activation: the transformers' norm -> proj_in): at dim 320 and level-0 row
+        counts the statistics pass plus one kernel that normalises in registers, otherwise GroupNorm + GEMM."""
+        if _LN_FUSED and pw.K == 320 and pw.N % 32 == 0 and x.shape[0] >= 32768 and rpi % 128 == 0:
+            st = self._arena.get("gn_stats", n_inst * 32 * 2, 1, torch.float32, x.device)
+            ops.groupnorm_stats(x, st, groups=32, n_inst=n_inst, rows_per_inst=rpi, eps=1e-6)
+            return ops.gn_linear320(x, gnw[0], gnw[1], st, pw, out, groups=32, rows_per_inst=rpi)
+        return ops.gemm(self._gn(x, gnw, "gn", n_inst=n_inst, rpi=rpi, eps=1e-6, silu=False), pw, out)
+
     def _attn_self_spatial(self, Wa, ln, h, g, heads):
         A = self._arena
         M, dev, Cc = h.shape[0], h.device, heads * 64
@@ -430,8 +439,7 @@ class UNetModel(nn.Module):
         context (identical for all guidance branches of one latent)."""
         A = self._arena
         M, dev, Cc = x.shape[0], x.device, x.shape[1]
-        n = self._gn(x, W["norm"], "gn", n_inst=g["F"], rpi=g["HW"], eps=1e-6, silu=False)
-        h = ops.gemm(n, W["proj_in"], A.get("tr_h", M, Cc, device=dev))
+        h = self._gn_linear(x, W["norm"], W["proj_in"], A.get("tr_h", M, Cc, device=dev), n_inst=g["F"], rpi=g["HW"])
         B_ = W["blk"]
         return self._attn_self_spatial(B_["attn1"], B_["norm1"], h, g, heads)
 
@@ -482,8 +490,8 @@ class UNetModel(nn.Module):
         A = self._arena
         M, dev, Cc = x.shape[0], x.device, x.shape[1]
         inner = W["proj_in"].N
-        n = self._gn(x, W["norm"], "gn", n_inst=g["B"], rpi=g["T"] * g["HW"], eps=1e-6, silu=False)
-        h = ops.gemm(n, W["proj_in"], A.get("tr_h", M, inner, device=dev))
+        h = self._gn_linear(x, W["norm"], W["proj_in"], A.get("tr_h", M, inner, device=dev), n_inst=g["B"],
+                            rpi=g["T"] * g["HW"])
         B_ = W["blk"]
         h = self._attn_self_temporal(B_["attn1"], B_["norm1"], h, g, heads)
         h = self._attn_self_temporal(B_["attn2"], B_["norm2"], h, g, heads)

@@ -438,6 +438,32 @@ def ln_linear320(x, pw, out, ln=None, ln_eps=1e-5):
     return out
 
 
+def groupnorm_stats(x, stats, *, groups, n_inst, rows_per_inst, eps):
+    """(mean, rstd) per (instance, group) of channels-last rows -> stats fp32 [n_inst, groups, 2] (for gn_linear320)."""
+    _rows(x, "x")
+    Cc = x.shape[1]
+    _need_rows(x, n_inst * rows_per_inst, Cc, "x"); _need(stats, n_inst * groups * 2, "stats")
+    l = _hip.lib()
+    ws = _gn_workspace(x.device, int(l.dc_groupnorm_workspace_bytes(n_inst, groups, rows_per_inst)))
+    _launch("groupnorm_stats(2 kernels)", 0.0, 2.0 * n_inst * rows_per_inst * Cc, l.dc_groupnorm_stats, _ptr(x), x.stride(0),
+            Cc, groups, n_inst, rows_per_inst, eps, _ptr(ws), _ptr(stats), stream_ptr())
+    return stats
+
+
+def gn_linear320(x, gamma, beta, stats, pw, out, *, groups, rows_per_inst):
+    """out = Linear(GroupNorm(x)) for dim 320 with the statistics of groupnorm_stats, normalisation applied in registers."""
+    _rows(x, "x"); _rows(out, "out")
+    M = x.shape[0]
+    if pw.K != 320 or pw.N % 32 or rows_per_inst % 128 or M % rows_per_inst:
+        raise ValueError("gn_linear320: K = 320, N % 32 == 0, rows_per_inst % 128 == 0, M % rows_per_inst == 0")
+    _need_rows(x, M, 320, "x"); _need_rows(out, M, pw.N, "out")
+    _need(gamma, 320, "gamma"); _need(beta, 320, "beta"); _need(stats, (M // rows_per_inst) * groups * 2, "stats")
+    _launch("gn_linear320", 2.0 * M * pw.N * 320, 2.0 * M * (320 + pw.N) + 2.0 * pw.N * 320, _hip.lib().dc_gn_linear320,
+            _ptr(x), x.stride(0), _ptr(gamma), _ptr(beta), _ptr(stats), groups, rows_per_inst, _ptr(pw.w), _ptr(pw.bias),
+            _ptr(out), out.stride(0), M, pw.N, stream_ptr())
+    return out
+
+
 def attn_small(q, k, v, o, *, batch, heads, Lq, Lk, d, scale, causal=False):
     """Any-head-width attention (CLIP towers): q/o rows [batch*Lq, >= heads*d], k/v rows [batch*Lk, >= heads*d]."""
     for t, n in ((q, "q"), (k, "k"), (v, "v"), (o, "o")):

@@ -204,6 +204,16 @@ int dc_ff_geglu_fused320(const uint16_t* x, int ldx, const float* ln_gamma, cons
 int dc_ln_linear320(const uint16_t* x, int ldx, const float* ln_gamma, const float* ln_beta, float ln_eps, const uint16_t* w,
                     const float* bias, uint16_t* out, int ldo, int M, int N, void* stream);
 
+/* GroupNorm (no activation) + Linear for dim = 320: out = GroupNorm(x) W^T (+ bias) with the statistics computed by
+ * dc_groupnorm_stats (fp32 [n_inst][groups][2] = mean, rstd); rows_per_inst % 128 == 0 and M % rows_per_inst == 0 (a
+ * 128-row tile never straddles two instances). Same rounding points as dc_groupnorm followed by dc_gemm_conv.
+ * replaces SpatialTransformer.forward norm -> proj_in lvdm/modules/attention.py:296-301 and TemporalTransformer.forward
+ * norm -> proj_in :367-377 at the UNet's level 0 */
+int dc_groupnorm_stats(const uint16_t* x, int ldx, int C, int groups, int n_inst, int rows_per_inst, float eps,
+                       float* workspace, float* stats_out, void* stream);
+int dc_gn_linear320(const uint16_t* x, int ldx, const float* gamma, const float* beta, const float* stats, int groups,
+                    int rows_per_inst, const uint16_t* w, const float* bias, uint16_t* out, int ldo, int M, int N, void* stream);
+
 /* ---- conditioning encoders (once per clip) ---------------------------------------------------- */
 
 /* Multi-head attention for any (even) head width d <= 256 and Lk <= 1024, optional causal mask (key j visible to query

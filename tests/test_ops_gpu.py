@@ -670,6 +670,35 @@ def test_ln_linear320_vs_layernorm_plus_gemm(ops, M, N):
         assert rel_l2(out, want) < 1e-3
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_inst,rpi,N", [(3, 256, 320), (2, 9216, 320), (5, 128, 64)])
+def test_gn_linear320_vs_groupnorm_plus_gemm(ops, n_inst, rpi, N):
+    """dc_groupnorm_stats + dc_gn_linear320 = dc_groupnorm + dc_gemm_conv (same rounding points) = torch fp32 reference"""
+    g = torch.Generator().manual_seed(n_inst * rpi + N)
+    M = n_inst * rpi
+    x = (torch.randn(M, 320, generator=g) * (1 + torch.arange(320) % 7 * 0.3) + 0.5).to(torch.bfloat16)
+    w = torch.randn(N, 320, generator=g) * 320 ** -0.5
+    b = torch.randn(N, generator=g) * 0.1
+    gam = (1 + 0.2 * torch.randn(320, generator=g)).to(DEV); bet = (0.3 * torch.randn(320, generator=g)).to(DEV)
+    pw = ops.PackedWeight.linear(w, b, DEV)
+    xd = x.to(DEV)
+    st = torch.empty(n_inst * 32 * 2, dtype=torch.float32, device=DEV)
+    ops.groupnorm_stats(xd, st, groups=32, n_inst=n_inst, rows_per_inst=rpi, eps=1e-6)
+    out = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+    ops.gn_linear320(xd, gam, bet, st, pw, out, groups=32, rows_per_inst=rpi)
+    n = torch.empty_like(xd)
+    ops.groupnorm(xd, n, gam, bet, groups=32, n_inst=n_inst, rows_per_inst=rpi, eps=1e-6, silu=False)
+    want = torch.empty_like(out)
+    ops.gemm(n, pw, want)
+    assert rel_l2(out, want) < 2e-3
+    xf = x.float().reshape(n_inst, rpi, 320).permute(0, 2, 1)
+    ref = torch.nn.functional.group_norm(xf, 32, gam.cpu(), bet.cpu(), 1e-6).permute(0, 2, 1).reshape(M, 320)
+    ref = torch.nn.functional.linear(ref, w, b)
+    assert rel_l2(out.float().cpu(), ref) < 6e-3
+    with pytest.raises(ValueError):
+        ops.gn_linear320(xd, gam, bet, st, pw, out, groups=32, rows_per_inst=rpi + 8)
+
+
 @pytest.mark.parametrize("M", [128 * 5, 1000, 40000])
 def test_ff_geglu_fused320_vs_torch(ops, M):
     """ff1 -> GEGLU -> ff2 (+ residual) in one kernel (dim 320) vs fp32 torch and vs the two-GEMM path."""
