@@ -71,23 +71,24 @@ __device__ __forceinline__ void glds16f(const void* gsrc, unsigned lds_dst_unifo
 // LayerNorm of the rows held as X fragments (lanes (fr, 0) and (fr, 1) hold the two halves of row fr), two-pass in
 // registers (BasicTransformerBlock norm1/2/3, lvdm/modules/attention.py:225-227, eps 1e-5); the result is rounded to bf16
 // exactly where the stand-alone LayerNorm kernel rounds its output.
-__device__ __forceinline__ void ln_rows_inplace(bf16x8_t (&xf)[FD / 16], const float* ln_g, const float* ln_b, float eps, int fh) {
+template <int KD>
+__device__ __forceinline__ void ln_rows_inplace(bf16x8_t (&xf)[KD / 16], const float* ln_g, const float* ln_b, float eps, int fh) {
     float sum = 0.f;
 #pragma unroll
-    for (int kk = 0; kk < FD / 16; ++kk) {
+    for (int kk = 0; kk < KD / 16; ++kk) {
         const u32x4_t w = __builtin_bit_cast(u32x4_t, xf[kk]);
 #pragma unroll
         for (int e = 0; e < 4; ++e) sum += __uint_as_float(w[e] << 16) + __uint_as_float(w[e] & 0xffff0000u);
     }
     sum += __shfl_xor(sum, 32, 64);
-    const float mean = sum * (1.0f / FD);
+    const float mean = sum * (1.0f / KD);
     // (opaque re-definitions between the passes: otherwise the 160 fp32 conversions of pass one are kept alive for passes
     // two and three - 160 more registers than the kernels have)
 #pragma unroll
-    for (int kk = 0; kk < FD / 16; ++kk) asm volatile("" : "+v"(xf[kk]));
+    for (int kk = 0; kk < KD / 16; ++kk) asm volatile("" : "+v"(xf[kk]));
     float q = 0.f;
 #pragma unroll
-    for (int kk = 0; kk < FD / 16; ++kk) {
+    for (int kk = 0; kk < KD / 16; ++kk) {
         const u32x4_t w = __builtin_bit_cast(u32x4_t, xf[kk]);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -96,11 +97,11 @@ __device__ __forceinline__ void ln_rows_inplace(bf16x8_t (&xf)[FD / 16], const f
         }
     }
     q += __shfl_xor(q, 32, 64);
-    const float rstd = rsqrtf(q * (1.0f / FD) + eps);
+    const float rstd = rsqrtf(q * (1.0f / KD) + eps);
 #pragma unroll
-    for (int kk = 0; kk < FD / 16; ++kk) asm volatile("" : "+v"(xf[kk]));
+    for (int kk = 0; kk < KD / 16; ++kk) asm volatile("" : "+v"(xf[kk]));
 #pragma unroll
-    for (int kk = 0; kk < FD / 16; ++kk) {
+    for (int kk = 0; kk < KD / 16; ++kk) {
         // gamma / beta in groups of 5 k steps (80 floats in flight): hoisted all at once they are 320 registers
         if (kk % 5 == 0) asm volatile("" ::: "memory");
         const u32x4_t w = __builtin_bit_cast(u32x4_t, xf[kk]);
@@ -119,9 +120,10 @@ __device__ __forceinline__ void ln_rows_inplace(bf16x8_t (&xf)[FD / 16], const f
 
 // x * a[c] + b[c] on the rows held as X fragments (GroupNorm with the statistics already known: a = gamma rstd,
 // b = beta - mean a, the arithmetic of gn_apply_kernel in norms.hip), rounded to bf16 like that kernel's output
-__device__ __forceinline__ void affine_rows_inplace(bf16x8_t (&xf)[FD / 16], const float* a, const float* b, int fh) {
+template <int KD>
+__device__ __forceinline__ void affine_rows_inplace(bf16x8_t (&xf)[KD / 16], const float* a, const float* b, int fh) {
 #pragma unroll
-    for (int kk = 0; kk < FD / 16; ++kk) {
+    for (int kk = 0; kk < KD / 16; ++kk) {
         if (kk % 5 == 0) asm volatile("" ::: "memory");
         const u32x4_t w = __builtin_bit_cast(u32x4_t, xf[kk]);
         const int c0 = kk * 16 + fh * 8;
@@ -229,7 +231,7 @@ void ff_geglu_fused320_kernel(const FfParams p) {
             const bf16_t* xr = p.X + (size_t)mr * p.ldx + fh * 8;
 #pragma unroll
             for (int kk = 0; kk < FD / 16; ++kk) xf[kk] = *reinterpret_cast<const bf16x8_t*>(xr + kk * 16);
-            if constexpr (LN) ln_rows_inplace(xf, p.ln_g, p.ln_b, p.ln_eps, fh);
+            if constexpr (LN) ln_rows_inplace<FD>(xf, p.ln_g, p.ln_b, p.ln_eps, fh);
         }
         f32x16_t acc[FD / 32];
 #pragma unroll
@@ -485,34 +487,40 @@ void ff_geglu_fused320_kernel(const FfParams p) {
 
 
 // ---------------------------------------------------------------------------------------------------------------------
-// LayerNorm + Linear for dim = 320 (level-0 transformers): out[M, N] = LayerNorm(x) W^T (+ bias), N a multiple of 32.
+// Norm + Linear for dim K = 320 or 640 (level-0 / level-1 transformers): out[M, N] = norm(x) W^T (+ bias), N % 32 == 0,
+// norm = LayerNorm over the row, or GroupNorm with known statistics (a per-instance affine map), or none.
 //   reference: norm1 -> attn1.to_q/k/v, norm2 -> attn2.to_q (and the temporal blocks' two self-attentions),
-//   BasicTransformerBlock._forward lvdm/modules/attention.py:242-245 with CrossAttention.forward :101-105
-// As LayerNorm kernel + GEMM the normalised copy is written and read back (2 x 189 MB per use at the 1024 config) and the
-// GEMM's 256 x 320 tiles read every activation row N / 320 times. Here a workgroup owns 128 rows for the whole N: the
-// (normalised) X fragments of a wave's 32 rows stay in registers as in the FeedForward kernel above, the weight streams
-// through a two-deep LDS ring in chunks of 32 output channels (20 KB, 20 MFMAs per wave), each chunk's 32 x 32 block is
-// stored row-major through a wave-private LDS patch. 50 KB of LDS and 153 registers: three workgroups per CU, i.e. three
-// waves per SIMD that are never in step, which hides the X loads at the head of a tile and the stores of the epilogue.
-// The kernel is bound by the HBM writes of `out` (N / 320 x 189 MB), not by the matrix pipe.
+//   BasicTransformerBlock._forward lvdm/modules/attention.py:242-245 with CrossAttention.forward :101-105; norm -> proj_in of
+//   SpatialTransformer.forward :296-301 / TemporalTransformer.forward :367-377
+// As norm kernel + GEMM the normalised copy is written and read back (2 x 189 MB per use at level 0 of the 1024 config) and
+// the GEMM's 256 x 320 tiles read every activation row N / 320 times. Here a workgroup owns 128 rows: the (normalised) X
+// fragments of a wave's 32 rows stay in registers as in the FeedForward kernel above, the weight streams through a
+// two-deep LDS ring in stages of 32 output channels x 320 k (20 KB, 20 MFMAs per wave; K = 640: two stages per chunk),
+// each chunk's 32 x 32 block is stored row-major through a wave-private LDS patch. ~50 KB of LDS and 153 (K = 320) / < 256
+// (K = 640) registers: three / two workgroups per CU, i.e. waves on a SIMD that are never in step, which hides the X loads
+// at the head of a tile and the stores of the epilogue. At K = 320 the kernel is bound by the HBM writes of `out`, not by
+// the matrix pipe. A launch with few row tiles splits N over `nsplit` workgroups per tile (level 1: 576 tiles for 512
+// slots would leave the second round almost empty).
 constexpr int LCH = 32;                        // output channels per chunk
 constexpr int LW_STAGE = LCH * FD * 2;         // 20 KB: 5 K tiles of [32 rows][128 B]
-constexpr int LL_LDS = 2 * LW_STAGE + 4 * 2048 + 2 * FD * 4;      // ring + epilogue patches + LayerNorm gamma / beta
+constexpr int ll_lds(int kh) { return 2 * LW_STAGE + 4 * 2048 + 2 * FD * kh * 4; }      // ring + epilogue patches + gamma / beta
 
 struct LlParams {
     const bf16_t* X; int ldx;
-    const bf16_t* W;             // [>= N][320]
+    const bf16_t* W;             // [>= N][K]
     const float* bias;           // [N] or nullptr
     bf16_t* O; int ldo;
     int M, N;
+    int nsplit, cpp;             // workgroups per row tile, chunks per workgroup
     const float* ln_g; const float* ln_b; float ln_eps;      // LayerNorm / GroupNorm gamma, beta
     const float2* gn_stats; int gn_groups, gn_rpi;           // NORM 2: (mean, rstd) [inst][group], rows per instance (% 128 == 0)
 };
 
-// NORM 0: none, 1: LayerNorm over the row, 2: GroupNorm with known statistics (a per-instance affine map)
-template <int NORM>
-__global__ __launch_bounds__(256, 3)
-void ln_linear320_kernel(const LlParams p) {
+// NORM 0: none, 1: LayerNorm over the row, 2: GroupNorm with known statistics; K = 320 KH
+template <int NORM, int KH>
+__global__ __launch_bounds__(256, KH == 1 ? 3 : 2)
+void norm_linear_kernel(const LlParams p) {
+    constexpr int KD = FD * KH;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -520,17 +528,21 @@ void ln_linear320_kernel(const LlParams p) {
     const int fr = lane & 31, fh = lane >> 5;
     const unsigned lds_base = (unsigned)(unsigned long)((lds_char_t*)smem);
     char* const ebuf = smem + 2 * LW_STAGE + wave * 2048;
-    const int m0 = blockIdx.x * FBM + wave * 32;
-    const bool full_tile = (int)blockIdx.x * FBM + FBM <= p.M;         // ragged last tile: uncounted vmcnt waits
-    const int nch = p.N / LCH;
+    const int tile = (int)blockIdx.x / p.nsplit, part = (int)blockIdx.x - tile * p.nsplit;
+    const int m0 = tile * FBM + wave * 32;
+    const bool full_tile = tile * FBM + FBM <= p.M;                    // ragged last tile: uncounted vmcnt waits
+    const int c_begin = part * p.cpp;
+    int c_end = c_begin + p.cpp;
+    if (c_end > p.N / LCH) c_end = p.N / LCH;
+    if (c_begin >= c_end) return;
 
-    // LDS-DMA of chunk c: 32 weight rows x 640 B = 20 pieces of 8 rows x 128 B, 5 per wave
+    // LDS-DMA of stage (chunk c, k half h): 32 weight rows x 640 B = 20 pieces of 8 rows x 128 B, 5 per wave
     unsigned vo[5];
 #pragma unroll
     for (int i = 0; i < 5; ++i) {
         const int u = wave * 5 + i;                      // (K tile t, 8-row group g): LDS offset u * 1024
         const int t = u >> 2, g = u & 3;
-        vo[i] = (unsigned)((g * 8 + (lane >> 3)) * (FD * 2) + t * 128 + (((lane & 7) ^ ((g * 4 + (lane >> 4)) & 7)) << 4));
+        vo[i] = (unsigned)((g * 8 + (lane >> 3)) * (KD * 2) + t * 128 + (((lane & 7) ^ ((g * 4 + (lane >> 4)) & 7)) << 4));
         asm volatile("" : "+v"(vo[i]));
     }
     auto dma_piece = [&](unsigned lds_dst, unsigned voff, uint64_t sbase) __attribute__((always_inline)) {
@@ -545,66 +557,72 @@ void ln_linear320_kernel(const LlParams p) {
             : "s"(lds_dst), "v"(voff), "s"(sbase)
             : "memory");
     };
-    auto w_base = [&](int c) { return (uint64_t)(uintptr_t)p.W + (uint64_t)c * (LCH * FD * 2); };
-    auto w_dst = [&](int c, int i) { return lds_base + (c & 1) * LW_STAGE + (wave * 5 + i) * 1024; };
+    auto w_base = [&](int c, int h) { return (uint64_t)(uintptr_t)p.W + (uint64_t)c * (LCH * KD * 2) + h * (FD * 2); };
+    auto w_dst = [&](int slot, int i) { return lds_base + slot * LW_STAGE + (wave * 5 + i) * 1024; };
 
 #pragma unroll
-    for (int i = 0; i < 5; ++i) dma_piece(w_dst(0, i), vo[i], w_base(0));
+    for (int i = 0; i < 5; ++i) dma_piece(w_dst(0, i), vo[i], w_base(c_begin, 0));
 
     // ---- X fragments of this wave's 32 rows (B operand: lane (row fr, half fh) holds k = 16 kk + 8 fh .. + 7)
-    bf16x8_t xf[FD / 16];
+    bf16x8_t xf[KD / 16];
     float* const lns = reinterpret_cast<float*>(smem + 2 * LW_STAGE + 4 * 2048);
     {
         int mr = m0 + fr;
         if (mr >= p.M) mr = p.M - 1;
         const bf16_t* xr = p.X + (size_t)mr * p.ldx + fh * 8;
 #pragma unroll
-        for (int kk = 0; kk < FD / 16; ++kk) xf[kk] = *reinterpret_cast<const bf16x8_t*>(xr + kk * 16);
+        for (int kk = 0; kk < KD / 16; ++kk) xf[kk] = *reinterpret_cast<const bf16x8_t*>(xr + kk * 16);
         if constexpr (NORM == 1) {
-            for (int i = tid; i < FD; i += 256) { lns[i] = p.ln_g[i]; lns[FD + i] = p.ln_b[i]; }
+            for (int i = tid; i < KD; i += 256) { lns[i] = p.ln_g[i]; lns[KD + i] = p.ln_b[i]; }
         } else if constexpr (NORM == 2) {
-            const int inst = (int)(((long long)blockIdx.x * FBM) / p.gn_rpi);      // a tile never straddles two instances
-            for (int i = tid; i < FD; i += 256) {
-                const float2 st = p.gn_stats[(size_t)inst * p.gn_groups + i / (FD / p.gn_groups)];
+            const int inst = (int)(((long long)tile * FBM) / p.gn_rpi);           // a tile never straddles two instances
+            for (int i = tid; i < KD; i += 256) {
+                const float2 st = p.gn_stats[(size_t)inst * p.gn_groups + i / (KD / p.gn_groups)];
                 const float a = p.ln_g[i] * st.y;
-                lns[i] = a; lns[FD + i] = p.ln_b[i] - st.x * a;
+                lns[i] = a; lns[KD + i] = p.ln_b[i] - st.x * a;
             }
         }
     }
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");     // X, gamma / beta and W(0): the compiler's own vmcnt
-    __builtin_amdgcn_s_barrier();                                   // accounting does not see the asm LDS-DMA, so the
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");     // X, gamma / beta and the first stage: the compiler's own
+    __builtin_amdgcn_s_barrier();                                   // vmcnt accounting does not see the asm LDS-DMA, so the
     asm volatile("" ::: "memory");                                  // loads are waited for explicitly
-    if constexpr (NORM == 1) ln_rows_inplace(xf, lns, lns + FD, p.ln_eps, fh);
-    if constexpr (NORM == 2) affine_rows_inplace(xf, lns, lns + FD, fh);
+    if constexpr (NORM == 1) ln_rows_inplace<KD>(xf, lns, lns + KD, p.ln_eps, fh);
+    if constexpr (NORM == 2) affine_rows_inplace<KD>(xf, lns, lns + KD, fh);
 
     constexpr int PD = 6;
-    for (int c = 0; c < nch; ++c) {
-        if (c > 0) {
-            // W(c) was issued during chunk c-1, in front of that chunk's two stores
-            if (full_tile) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            asm volatile("" ::: "memory");
-        }
-        const char* s1 = smem + (c & 1) * LW_STAGE;
+    int slot = 0;
+    for (int c = c_begin; c < c_end; ++c) {
         f32x16_t acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-        bf16x8_t wr[PD];
-        auto rd = [&](int kk, int slot) __attribute__((always_inline)) {
-            wr[slot] = *(lds_vfrag_t*)((lds_char_t*)s1 + (kk >> 2) * 4096 + off128(fr, (kk & 3) * 2 + fh));
-        };
 #pragma unroll
-        for (int kk = 0; kk < PD; ++kk) rd(kk, kk);
-        const bool more = c + 1 < nch;
-        const uint64_t nb = w_base(c + 1);
+        for (int h = 0; h < KH; ++h) {
+            if (c > c_begin || h > 0) {
+                // this stage was issued during the previous one, in front of that stage's two stores if it closed a chunk
+                if (!full_tile) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                else if (h == 0) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+            }
+            const char* s1 = smem + slot * LW_STAGE;
+            bf16x8_t wr[PD];
+            auto rd = [&](int kk, int sl) __attribute__((always_inline)) {
+                wr[sl] = *(lds_vfrag_t*)((lds_char_t*)s1 + (kk >> 2) * 4096 + off128(fr, (kk & 3) * 2 + fh));
+            };
 #pragma unroll
-        for (int kk = 0; kk < FD / 16; ++kk) {
-            bf16x8_t f = wr[kk % PD];
-            if (kk + PD < FD / 16) rd(kk + PD, kk % PD);
-            asm volatile("" : "+v"(f));
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f, xf[kk], acc, 0, 0, 0);
-            if (kk < 5 && more) dma_piece(w_dst(c + 1, kk), vo[kk], nb);
+            for (int kk = 0; kk < PD; ++kk) rd(kk, kk);
+            const bool more = h + 1 < KH || c + 1 < c_end;
+            const uint64_t nb = h + 1 < KH ? w_base(c, h + 1) : w_base(c + 1, 0);
+#pragma unroll
+            for (int kk = 0; kk < FD / 16; ++kk) {
+                bf16x8_t f = wr[kk % PD];
+                if (kk + PD < FD / 16) rd(kk + PD, kk % PD);
+                asm volatile("" : "+v"(f));
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f, xf[h * (FD / 16) + kk], acc, 0, 0, 0);
+                if (kk < 5 && more) dma_piece(w_dst(slot ^ 1, kk), vo[kk], nb);
+            }
+            slot ^= 1;
         }
         // ---- chunk epilogue: + bias, bf16, row-major 16-byte stores through the wave-private patch (32 rows x 64 B)
         {
@@ -670,49 +688,60 @@ extern "C" int dc_ff_geglu_fused320(const uint16_t* x, int ldx, const float* ln_
     return 0;
 }
 
-static int launch_norm_linear320(int norm, const LlParams& p, hipStream_t stream) {
+template <int NORM, int KH>
+static int launch_norm_linear_t(const LlParams& p, dim3 grid, hipStream_t stream) {
     static bool configured = false;
     if (!configured) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ln_linear320_kernel<0>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, LL_LDS);
-        if (e == hipSuccess)
-            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ln_linear320_kernel<1>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, LL_LDS);
-        if (e == hipSuccess)
-            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ln_linear320_kernel<2>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, LL_LDS);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&norm_linear_kernel<NORM, KH>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, ll_lds(KH));
         if (e != hipSuccess) return (int)e;
         configured = true;
     }
-    const dim3 grid((p.M + FBM - 1) / FBM);
-    if (norm == 1) hipLaunchKernelGGL(ln_linear320_kernel<1>, grid, dim3(256), LL_LDS, stream, p);
-    else if (norm == 2) hipLaunchKernelGGL(ln_linear320_kernel<2>, grid, dim3(256), LL_LDS, stream, p);
-    else hipLaunchKernelGGL(ln_linear320_kernel<0>, grid, dim3(256), LL_LDS, stream, p);
+    hipLaunchKernelGGL((norm_linear_kernel<NORM, KH>), grid, dim3(256), ll_lds(KH), stream, p);
     DC_CHECK_LAUNCH();
     return 0;
 }
 
-extern "C" int dc_ln_linear320(const uint16_t* x, int ldx, const float* ln_gamma, const float* ln_beta, float ln_eps,
-                               const uint16_t* w, const float* bias, uint16_t* out, int ldo, int M, int N, void* stream_) {
+static int launch_norm_linear(int norm, int K, LlParams& p, hipStream_t stream) {
+    // few row tiles: split N over several workgroups per tile until the launch has >= 3 rounds of work for its slots
+    const int tiles = (p.M + FBM - 1) / FBM, nch = p.N / LCH;
+    const int slots = 256 * (K == FD ? 3 : 2);
+    int nsplit = 1;
+    while (tiles * nsplit < 3 * slots && nsplit * 2 <= nch && nch / (nsplit * 2) >= 5) nsplit *= 2;
+    p.nsplit = nsplit;
+    p.cpp = (nch + nsplit - 1) / nsplit;
+    const dim3 grid(tiles * nsplit);
+    if (K == FD) {
+        if (norm == 1) return launch_norm_linear_t<1, 1>(p, grid, stream);
+        if (norm == 2) return launch_norm_linear_t<2, 1>(p, grid, stream);
+        return launch_norm_linear_t<0, 1>(p, grid, stream);
+    }
+    if (norm == 1) return launch_norm_linear_t<1, 2>(p, grid, stream);
+    if (norm == 2) return launch_norm_linear_t<2, 2>(p, grid, stream);
+    return launch_norm_linear_t<0, 2>(p, grid, stream);
+}
+
+extern "C" int dc_ln_linear(const uint16_t* x, int ldx, int K, const float* ln_gamma, const float* ln_beta, float ln_eps,
+                            const uint16_t* w, const float* bias, uint16_t* out, int ldo, int M, int N, void* stream_) {
     if (!x || !w || !out || ((ln_gamma == nullptr) != (ln_beta == nullptr))) return DC_ERR_ARG;
-    if (M < 1 || N < LCH || N % LCH || ldx % 8 || ldo % 8) return DC_ERR_SHAPE;
+    if ((K != FD && K != 2 * FD) || M < 1 || N < LCH || N % LCH || ldx % 8 || ldo % 8) return DC_ERR_SHAPE;
     if (((uintptr_t)x | (uintptr_t)out | (uintptr_t)w) % 16) return DC_ERR_SHAPE;
     LlParams p;
     p.X = x; p.ldx = ldx; p.W = w; p.bias = bias; p.O = out; p.ldo = ldo; p.M = M; p.N = N;
     p.ln_g = ln_gamma; p.ln_b = ln_beta; p.ln_eps = ln_eps; p.gn_stats = nullptr; p.gn_groups = 1; p.gn_rpi = FBM;
-    return launch_norm_linear320(ln_gamma ? 1 : 0, p, (hipStream_t)stream_);
+    return launch_norm_linear(ln_gamma ? 1 : 0, K, p, (hipStream_t)stream_);
 }
 
-extern "C" int dc_gn_linear320(const uint16_t* x, int ldx, const float* gamma, const float* beta, const float* stats,
-                               int groups, int rows_per_inst, const uint16_t* w, const float* bias, uint16_t* out, int ldo,
-                               int M, int N, void* stream_) {
+extern "C" int dc_gn_linear(const uint16_t* x, int ldx, int K, const float* gamma, const float* beta, const float* stats,
+                            int groups, int rows_per_inst, const uint16_t* w, const float* bias, uint16_t* out, int ldo,
+                            int M, int N, void* stream_) {
     if (!x || !w || !out || !gamma || !beta || !stats) return DC_ERR_ARG;
-    if (M < 1 || N < LCH || N % LCH || ldx % 8 || ldo % 8) return DC_ERR_SHAPE;
-    if (groups < 1 || FD % groups || rows_per_inst < FBM || rows_per_inst % FBM || M % rows_per_inst) return DC_ERR_SHAPE;
+    if ((K != FD && K != 2 * FD) || M < 1 || N < LCH || N % LCH || ldx % 8 || ldo % 8) return DC_ERR_SHAPE;
+    if (groups < 1 || K % groups || rows_per_inst < FBM || rows_per_inst % FBM || M % rows_per_inst) return DC_ERR_SHAPE;
     if (((uintptr_t)x | (uintptr_t)out | (uintptr_t)w) % 16) return DC_ERR_SHAPE;
     LlParams p;
     p.X = x; p.ldx = ldx; p.W = w; p.bias = bias; p.O = out; p.ldo = ldo; p.M = M; p.N = N;
     p.ln_g = gamma; p.ln_b = beta; p.ln_eps = 0.f;
     p.gn_stats = reinterpret_cast<const float2*>(stats); p.gn_groups = groups; p.gn_rpi = rows_per_inst;
-    return launch_norm_linear320(2, p, (hipStream_t)stream_);
+    return launch_norm_linear(2, K, p, (hipStream_t)stream_);
 }

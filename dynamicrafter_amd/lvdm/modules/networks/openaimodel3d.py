@@ -26,7 +26,8 @@ import os
 
 _BF16 = torch.bfloat16
 _FF_FUSED = os.environ.get("DC_FF_FUSED", "1") != "0"
-_LN_FUSED = os.environ.get("DC_LN_FUSED", "1") != "0"      # A/B switches of the dim-320 fused kernels (ff_fused.hip)
+_LN_FUSED = os.environ.get("DC_LN_FUSED", "1") != "0"      # A/B switches of the fused kernels in ff_fused.hip
+_LN_FUSED_K = tuple(int(k) for k in os.environ.get("DC_LN_FUSED_K", "320,640").split(","))
 C_IN_PAD = 64   # conv_in consumes the 8 latent+concat channels zero-padded to one 64-wide K slice
 
 
@@ -392,19 +393,19 @@ class UNetModel(nn.Module):
         return r
 
     def _ln_linear(self, h, ln, pw, out):
-        """Linear(LayerNorm(h)): at dim 320 and level-0 row counts one kernel with the LayerNorm in registers (the
+        """Linear(LayerNorm(h)): at dim 320 / 640 and level-0 / level-1 row counts one kernel with the LayerNorm in registers (the
         normalised copy never reaches HBM), otherwise LayerNorm kernel + GEMM."""
-        if _LN_FUSED and pw.K == 320 and pw.N % 32 == 0 and h.shape[0] >= 32768:
-            return ops.ln_linear320(h, pw, out, ln=ln, ln_eps=1e-5)
+        if _LN_FUSED and pw.K in _LN_FUSED_K and pw.N % 32 == 0 and h.shape[0] >= 32768:
+            return ops.ln_linear(h, pw, out, ln=ln, ln_eps=1e-5)
         return ops.gemm(self._ln(h, ln, "ln"), pw, out)
 
     def _gn_linear(self, x, gnw, pw, out, *, n_inst, rpi):
-        """Linear(GroupNorm(x)) (eps 1e-6, no activation: the transformers' norm -> proj_in): at dim 320 and level-0 row
-        counts the statistics pass plus one kernel that normalises in registers, otherwise GroupNorm + GEMM."""
-        if _LN_FUSED and pw.K == 320 and pw.N % 32 == 0 and x.shape[0] >= 32768 and rpi % 128 == 0:
+        """Linear(GroupNorm(x)) (eps 1e-6, no activation: the transformers' norm -> proj_in): at dim 320 / 640 and level-0 / level-1
+        row counts the statistics pass plus one kernel that normalises in registers, otherwise GroupNorm + GEMM."""
+        if _LN_FUSED and pw.K in _LN_FUSED_K and pw.N % 32 == 0 and x.shape[0] >= 32768 and rpi % 128 == 0:
             st = self._arena.get("gn_stats", n_inst * 32 * 2, 1, torch.float32, x.device)
             ops.groupnorm_stats(x, st, groups=32, n_inst=n_inst, rows_per_inst=rpi, eps=1e-6)
-            return ops.gn_linear320(x, gnw[0], gnw[1], st, pw, out, groups=32, rows_per_inst=rpi)
+            return ops.gn_linear(x, gnw[0], gnw[1], st, pw, out, groups=32, rows_per_inst=rpi)
         return ops.gemm(self._gn(x, gnw, "gn", n_inst=n_inst, rpi=rpi, eps=1e-6, silu=False), pw, out)
 
     def _attn_self_spatial(self, Wa, ln, h, g, heads):

@@ -422,19 +422,19 @@ def ff_geglu_fused320(x, pw1, w2p, b2, out, residual=None, ln=None, ln_eps=1e-5)
     return out
 
 
-def ln_linear320(x, pw, out, ln=None, ln_eps=1e-5):
-    """out = Linear(LayerNorm(x) if ln else x) for dim 320 in one launch; pw = PackedWeight.linear (K = 320, N % 32 == 0);
+def ln_linear(x, pw, out, ln=None, ln_eps=1e-5):
+    """out = Linear(LayerNorm(x) if ln else x) for dim 320 / 640 in one launch; pw = PackedWeight.linear (N % 32 == 0);
     ln = (gamma, beta) fp32 or None."""
     _rows(x, "x"); _rows(out, "out")
-    M = x.shape[0]
-    if pw.K != 320 or pw.N % 32:
-        raise ValueError("ln_linear320: K must be 320 and N a multiple of 32")
-    _need_rows(x, M, 320, "x"); _need_rows(out, M, pw.N, "out")
+    M, K = x.shape[0], pw.K
+    if K not in (320, 640) or pw.N % 32:
+        raise ValueError("ln_linear: K must be 320 or 640 and N a multiple of 32")
+    _need_rows(x, M, K, "x"); _need_rows(out, M, pw.N, "out")
     if ln is not None:
-        _need(ln[0], 320, "ln gamma"); _need(ln[1], 320, "ln beta")
-    _launch("ln_linear320", 2.0 * M * pw.N * 320, 2.0 * M * (320 + pw.N) + 2.0 * pw.N * 320, _hip.lib().dc_ln_linear320,
-            _ptr(x), x.stride(0), _ptr(None if ln is None else ln[0]), _ptr(None if ln is None else ln[1]), ln_eps, _ptr(pw.w),
-            _ptr(pw.bias), _ptr(out), out.stride(0), M, pw.N, stream_ptr())
+        _need(ln[0], K, "ln gamma"); _need(ln[1], K, "ln beta")
+    _launch("ln_linear", 2.0 * M * pw.N * K, 2.0 * M * (K + pw.N) + 2.0 * pw.N * K, _hip.lib().dc_ln_linear,
+            _ptr(x), x.stride(0), K, _ptr(None if ln is None else ln[0]), _ptr(None if ln is None else ln[1]), ln_eps,
+            _ptr(pw.w), _ptr(pw.bias), _ptr(out), out.stride(0), M, pw.N, stream_ptr())
     return out
 
 
@@ -450,16 +450,17 @@ def groupnorm_stats(x, stats, *, groups, n_inst, rows_per_inst, eps):
     return stats
 
 
-def gn_linear320(x, gamma, beta, stats, pw, out, *, groups, rows_per_inst):
-    """out = Linear(GroupNorm(x)) for dim 320 with the statistics of groupnorm_stats, normalisation applied in registers."""
+def gn_linear(x, gamma, beta, stats, pw, out, *, groups, rows_per_inst):
+    """out = Linear(GroupNorm(x)) for dim 320 / 640 with the statistics of groupnorm_stats, normalisation applied in
+    registers."""
     _rows(x, "x"); _rows(out, "out")
-    M = x.shape[0]
-    if pw.K != 320 or pw.N % 32 or rows_per_inst % 128 or M % rows_per_inst:
-        raise ValueError("gn_linear320: K = 320, N % 32 == 0, rows_per_inst % 128 == 0, M % rows_per_inst == 0")
-    _need_rows(x, M, 320, "x"); _need_rows(out, M, pw.N, "out")
-    _need(gamma, 320, "gamma"); _need(beta, 320, "beta"); _need(stats, (M // rows_per_inst) * groups * 2, "stats")
-    _launch("gn_linear320", 2.0 * M * pw.N * 320, 2.0 * M * (320 + pw.N) + 2.0 * pw.N * 320, _hip.lib().dc_gn_linear320,
-            _ptr(x), x.stride(0), _ptr(gamma), _ptr(beta), _ptr(stats), groups, rows_per_inst, _ptr(pw.w), _ptr(pw.bias),
+    M, K = x.shape[0], pw.K
+    if K not in (320, 640) or pw.N % 32 or rows_per_inst % 128 or M % rows_per_inst:
+        raise ValueError("gn_linear: K in (320, 640), N % 32 == 0, rows_per_inst % 128 == 0, M % rows_per_inst == 0")
+    _need_rows(x, M, K, "x"); _need_rows(out, M, pw.N, "out")
+    _need(gamma, K, "gamma"); _need(beta, K, "beta"); _need(stats, (M // rows_per_inst) * groups * 2, "stats")
+    _launch("gn_linear", 2.0 * M * pw.N * K, 2.0 * M * (K + pw.N) + 2.0 * pw.N * K, _hip.lib().dc_gn_linear,
+            _ptr(x), x.stride(0), K, _ptr(gamma), _ptr(beta), _ptr(stats), groups, rows_per_inst, _ptr(pw.w), _ptr(pw.bias),
             _ptr(out), out.stride(0), M, pw.N, stream_ptr())
     return out
 

@@ -196,23 +196,23 @@ int dc_ff_geglu_fused320(const uint16_t* x, int ldx, const float* ln_gamma, cons
                          const uint16_t* w1, const float* b1, const uint16_t* w2p, const float* b2, const uint16_t* residual,
                          int ldr, uint16_t* out, int ldo, int M, void* stream);
 
-/* LayerNorm + Linear for dim = 320: out[M,N] = n W^T (+ bias), n = x, or LayerNorm(x; ln_gamma, ln_beta, ln_eps) when
- * ln_gamma != NULL (rounded to bf16 like dc_layernorm's output); N % 32 == 0. x/out: bf16 rows (ld % 8 == 0, 16-byte
- * aligned); w: bf16 [>= N][320] as dc_gemm_conv takes a Linear weight; bias fp32 [N] or NULL.
- * replaces norm1 -> attn1.to_q/k/v (one [960, 320] weight) and norm2 -> attn2.to_q of BasicTransformerBlock._forward
- * lvdm/modules/attention.py:242-245 (CrossAttention.forward :101-105) at the UNet's level 0 */
-int dc_ln_linear320(const uint16_t* x, int ldx, const float* ln_gamma, const float* ln_beta, float ln_eps, const uint16_t* w,
-                    const float* bias, uint16_t* out, int ldo, int M, int N, void* stream);
-
-/* GroupNorm (no activation) + Linear for dim = 320: out = GroupNorm(x) W^T (+ bias) with the statistics computed by
- * dc_groupnorm_stats (fp32 [n_inst][groups][2] = mean, rstd); rows_per_inst % 128 == 0 and M % rows_per_inst == 0 (a
- * 128-row tile never straddles two instances). Same rounding points as dc_groupnorm followed by dc_gemm_conv.
- * replaces SpatialTransformer.forward norm -> proj_in lvdm/modules/attention.py:296-301 and TemporalTransformer.forward
- * norm -> proj_in :367-377 at the UNet's level 0 */
+/* Norm + Linear for dim K = 320 or 640: out[M,N] = n W^T (+ bias), N % 32 == 0; x/out: bf16 rows (ld % 8 == 0, 16-byte
+ * aligned); w: bf16 [>= N][K] as dc_gemm_conv takes a Linear weight; bias fp32 [N] or NULL. The normalised rows live in
+ * registers only (rounded to bf16 where dc_layernorm / dc_groupnorm round their outputs).
+ * dc_ln_linear: n = x, or LayerNorm(x; ln_gamma, ln_beta, ln_eps) when ln_gamma != NULL.
+ *   replaces norm1 -> attn1.to_q/k/v (one [3K, K] weight) and norm2 -> attn2.to_q of BasicTransformerBlock._forward
+ *   lvdm/modules/attention.py:242-245 (CrossAttention.forward :101-105) at the UNet's levels 0 and 1
+ * dc_gn_linear: n = GroupNorm(x) (no activation) with the statistics computed by dc_groupnorm_stats (fp32
+ *   [n_inst][groups][2] = mean, rstd); rows_per_inst % 128 == 0 and M % rows_per_inst == 0 (a 128-row tile never straddles
+ *   two instances).
+ *   replaces SpatialTransformer.forward norm -> proj_in lvdm/modules/attention.py:296-301 and TemporalTransformer.forward
+ *   norm -> proj_in :367-377 */
+int dc_ln_linear(const uint16_t* x, int ldx, int K, const float* ln_gamma, const float* ln_beta, float ln_eps, const uint16_t* w,
+                 const float* bias, uint16_t* out, int ldo, int M, int N, void* stream);
 int dc_groupnorm_stats(const uint16_t* x, int ldx, int C, int groups, int n_inst, int rows_per_inst, float eps,
                        float* workspace, float* stats_out, void* stream);
-int dc_gn_linear320(const uint16_t* x, int ldx, const float* gamma, const float* beta, const float* stats, int groups,
-                    int rows_per_inst, const uint16_t* w, const float* bias, uint16_t* out, int ldo, int M, int N, void* stream);
+int dc_gn_linear(const uint16_t* x, int ldx, int K, const float* gamma, const float* beta, const float* stats, int groups,
+                 int rows_per_inst, const uint16_t* w, const float* bias, uint16_t* out, int ldo, int M, int N, void* stream);
 
 /* ---- conditioning encoders (once per clip) ---------------------------------------------------- */
 

@@ -644,59 +644,61 @@ def test_cross_attn_dual_vs_torch(ops, B, heads, Lq, nt, ni, s2):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("M,N", [(128, 320), (40000, 960), (333, 64)])
-def test_ln_linear320_vs_layernorm_plus_gemm(ops, M, N):
-    """dc_ln_linear320 = dc_layernorm + dc_gemm_conv (same rounding points) and = torch fp32 LayerNorm + Linear"""
+@pytest.mark.parametrize("M,N,K", [(128, 320, 320), (40000, 960, 320), (333, 64, 320), (73728, 1920, 640), (300, 96, 640),
+                                   (4096, 640, 640)])
+def test_ln_linear_vs_layernorm_plus_gemm(ops, M, N, K):
+    """dc_ln_linear = dc_layernorm + dc_gemm_conv (same rounding points) and = torch fp32 LayerNorm + Linear"""
     g = torch.Generator().manual_seed(M + N)
-    x = (torch.randn(M, 320, generator=g) * 1.3 + 0.4).to(torch.bfloat16)
-    w = torch.randn(N, 320, generator=g) * 320 ** -0.5
+    x = (torch.randn(M, K, generator=g) * 1.3 + 0.4).to(torch.bfloat16)
+    w = torch.randn(N, K, generator=g) * K ** -0.5
     b = torch.randn(N, generator=g) * 0.1
-    gam = 1 + 0.2 * torch.randn(320, generator=g); bet = 0.3 * torch.randn(320, generator=g)
+    gam = 1 + 0.2 * torch.randn(K, generator=g); bet = 0.3 * torch.randn(K, generator=g)
     for bias in (None, b):
         pw = ops.PackedWeight.linear(w, bias, DEV)
         xd = x.to(DEV)
         out = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
-        ops.ln_linear320(xd, pw, out, ln=(gam.to(DEV), bet.to(DEV)))
+        ops.ln_linear(xd, pw, out, ln=(gam.to(DEV), bet.to(DEV)))
         n = torch.empty_like(xd)
         ops.layernorm(xd, n, gam.to(DEV), bet.to(DEV), 1e-5)
         want = torch.empty_like(out)
         ops.gemm(n, pw, want)
         assert rel_l2(out, want) < 2e-3
-        ref = torch.nn.functional.linear(torch.nn.functional.layer_norm(x.float(), (320,), gam, bet, 1e-5), w, bias)
+        ref = torch.nn.functional.linear(torch.nn.functional.layer_norm(x.float(), (K,), gam, bet, 1e-5), w, bias)
         assert rel_l2(out.float().cpu(), ref) < 6e-3
         # without the LayerNorm it is the plain Linear
-        ops.ln_linear320(xd, pw, out)
+        ops.ln_linear(xd, pw, out)
         ops.gemm(xd, pw, want)
         assert rel_l2(out, want) < 1e-3
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("n_inst,rpi,N", [(3, 256, 320), (2, 9216, 320), (5, 128, 64)])
-def test_gn_linear320_vs_groupnorm_plus_gemm(ops, n_inst, rpi, N):
-    """dc_groupnorm_stats + dc_gn_linear320 = dc_groupnorm + dc_gemm_conv (same rounding points) = torch fp32 reference"""
+@pytest.mark.parametrize("n_inst,rpi,N,K", [(3, 256, 320, 320), (2, 9216, 320, 320), (5, 128, 64, 320), (32, 2304, 640, 640),
+                                             (3, 384, 96, 640)])
+def test_gn_linear_vs_groupnorm_plus_gemm(ops, n_inst, rpi, N, K):
+    """dc_groupnorm_stats + dc_gn_linear = dc_groupnorm + dc_gemm_conv (same rounding points) = torch fp32 reference"""
     g = torch.Generator().manual_seed(n_inst * rpi + N)
     M = n_inst * rpi
-    x = (torch.randn(M, 320, generator=g) * (1 + torch.arange(320) % 7 * 0.3) + 0.5).to(torch.bfloat16)
-    w = torch.randn(N, 320, generator=g) * 320 ** -0.5
+    x = (torch.randn(M, K, generator=g) * (1 + torch.arange(K) % 7 * 0.3) + 0.5).to(torch.bfloat16)
+    w = torch.randn(N, K, generator=g) * K ** -0.5
     b = torch.randn(N, generator=g) * 0.1
-    gam = (1 + 0.2 * torch.randn(320, generator=g)).to(DEV); bet = (0.3 * torch.randn(320, generator=g)).to(DEV)
+    gam = (1 + 0.2 * torch.randn(K, generator=g)).to(DEV); bet = (0.3 * torch.randn(K, generator=g)).to(DEV)
     pw = ops.PackedWeight.linear(w, b, DEV)
     xd = x.to(DEV)
     st = torch.empty(n_inst * 32 * 2, dtype=torch.float32, device=DEV)
     ops.groupnorm_stats(xd, st, groups=32, n_inst=n_inst, rows_per_inst=rpi, eps=1e-6)
     out = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
-    ops.gn_linear320(xd, gam, bet, st, pw, out, groups=32, rows_per_inst=rpi)
+    ops.gn_linear(xd, gam, bet, st, pw, out, groups=32, rows_per_inst=rpi)
     n = torch.empty_like(xd)
     ops.groupnorm(xd, n, gam, bet, groups=32, n_inst=n_inst, rows_per_inst=rpi, eps=1e-6, silu=False)
     want = torch.empty_like(out)
     ops.gemm(n, pw, want)
     assert rel_l2(out, want) < 2e-3
-    xf = x.float().reshape(n_inst, rpi, 320).permute(0, 2, 1)
-    ref = torch.nn.functional.group_norm(xf, 32, gam.cpu(), bet.cpu(), 1e-6).permute(0, 2, 1).reshape(M, 320)
+    xf = x.float().reshape(n_inst, rpi, K).permute(0, 2, 1)
+    ref = torch.nn.functional.group_norm(xf, 32, gam.cpu(), bet.cpu(), 1e-6).permute(0, 2, 1).reshape(M, K)
     ref = torch.nn.functional.linear(ref, w, b)
     assert rel_l2(out.float().cpu(), ref) < 6e-3
     with pytest.raises(ValueError):
-        ops.gn_linear320(xd, gam, bet, st, pw, out, groups=32, rows_per_inst=rpi + 8)
+        ops.gn_linear(xd, gam, bet, st, pw, out, groups=32, rows_per_inst=rpi + 8)
 
 
 @pytest.mark.parametrize("M", [128 * 5, 1000, 40000])

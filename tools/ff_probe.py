@@ -30,12 +30,14 @@ for name, fn in (("pair", pair), ("fused", fused), ("ln+pair", ln_pair), ("lnfus
     us = e0.elapsed_time(e1) / 10 * 1e3
     print(f"{name:8s} M={M}: {us:8.1f} us  {2.0 * M * 3840 * 320 / us / 1e6:7.1f} TF/s", flush=True)
 
-# LayerNorm + Linear (dc_ln_linear320) vs LayerNorm kernel + GEMM
-for N in (960, 320):
-    pw = ops.PackedWeight.linear(torch.randn(N, 320, generator=g) * 320 ** -0.5, None, DEV)
-    o = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
-    def two(): ops.layernorm(h, x, gam, bet, 1e-5); ops.gemm(x, pw, o)
-    def one(): ops.ln_linear320(h, pw, o, ln=(gam, bet))
+# LayerNorm + Linear (dc_ln_linear) vs LayerNorm kernel + GEMM at the level-0 and level-1 shapes
+for (Mr, K, N) in ((M, 320, 960), (M, 320, 320), (M // 4, 640, 1920), (M // 4, 640, 640)):
+    pw = ops.PackedWeight.linear(torch.randn(N, K, generator=g) * K ** -0.5, None, DEV)
+    hh = torch.randn(Mr, K, device=DEV).to(torch.bfloat16); nn_ = torch.empty_like(hh)
+    gk = torch.ones(K, device=DEV); bk = torch.zeros(K, device=DEV)
+    o = torch.empty(Mr, N, dtype=torch.bfloat16, device=DEV)
+    def two(): ops.layernorm(hh, nn_, gk, bk, 1e-5); ops.gemm(nn_, pw, o)
+    def one(): ops.ln_linear(hh, pw, o, ln=(gk, bk))
     for name, fn in (("ln+gemm", two), ("ln_linear", one), ("ln+gemm", two), ("ln_linear", one)):
         for _ in range(2): fn()
         torch.cuda.synchronize()
@@ -44,4 +46,4 @@ for N in (960, 320):
         for _ in range(10): fn()
         e1.record(); torch.cuda.synchronize()
         us = e0.elapsed_time(e1) / 10 * 1e3
-        print(f"{name:10s} M={M} N={N}: {us:8.1f} us  {2.0 * M * N * 320 / us / 1e6:7.1f} TF/s  {2.0 * M * (320 + N) / us / 1e6:6.2f} TB/s", flush=True)
+        print(f"{name:10s} M={Mr} K={K} N={N}: {us:8.1f} us  {2.0 * Mr * N * K / us / 1e6:7.1f} TF/s  {2.0 * Mr * (K + N) / us / 1e6:6.2f} TB/s", flush=True)
