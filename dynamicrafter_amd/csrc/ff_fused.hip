@@ -41,6 +41,7 @@ constexpr int FF_LDS = 2 * W1_STAGE + W2_RING * W2_STAGE + 4 * 2048 + 2 * FM * 4
 static_assert(FF_LDS <= 160 * 1024, "LDS");
 
 typedef __attribute__((address_space(3))) char lds_char_t;
+typedef __attribute__((address_space(3))) bf16x4_t lds_bf16x4_t;
 typedef const volatile __attribute__((address_space(3))) bf16x8_t lds_vfrag_t;   // pinned LDS fragment load (see PD)
 __device__ __attribute__((aligned(16))) uint32_t g_zero_ff[8];
 #ifdef DC_FF_STAMPS          // tool build only (tools/ff_stamps.py): shader-clock totals of the four parts of a chunk iteration
@@ -648,6 +649,217 @@ void norm_linear_kernel(const LlParams p) {
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// LayerNorm + q/k/v projection + attention over the T = 16 frames of a spatial position, dim 320 (5 heads x 64), in ONE
+// launch: att[M, 320] = softmax_T(q k^T scale) v with q, k, v = LayerNorm(x) Wq^T, Wk^T, Wv^T.
+//   reference: TemporalTransformer.forward lvdm/modules/attention.py:365-412 -> BasicTransformerBlock._forward :242-244
+//   (norm1 / norm2 -> attn1 / attn2, both self-attention over time) -> CrossAttention.forward :101-125
+// As three kernels (LayerNorm, [M, 960] projection, temporal attention) the qkv tensor is written and read back: 2 x 566 MB
+// per attention at the 1024 config, 11 times per UNet forward. Here a workgroup owns 8 positions x 16 frames = 128 rows
+// (gathered: the frames of a position are HW rows apart), a wave 2 positions: its 32 (normalised) rows stay in registers
+// as X fragments (norm_linear_kernel), the weight streams through LDS head by head (q, k, v: 6 chunks of 32 columns).
+// The q and k blocks never leave registers: in accumulator layout a lane holds 16 of the 32 channels of ITS row, which
+// is an MFMA operand fragment once both factors agree on the k order - S^T = K Q^T is 4 MFMAs on the packed accumulators.
+// v goes through a wave-private LDS patch (transposed reads, as the flash kernel reads V^T); a 32 x 32 score block holds
+// the two positions' 16 x 16 problems on its diagonal, the rest is masked. bf16 roundings are where the three-kernel
+// path has them (q, k, v, P), the softmax is fp32.
+constexpr int TA_VLD = 192;                    // bytes per v row in the patch (flash kernel's V_LD)
+constexpr int TA_PATCH = 32 * TA_VLD;          // 6 KB per wave: v [32 rows][64 d], then the output rows of the head
+constexpr int TA_LDS = 2 * LW_STAGE + 4 * TA_PATCH + 2 * FD * 4;
+
+struct TaParams {
+    const bf16_t* X; int ldx;
+    const bf16_t* W;             // [>= 960][320]: to_q, to_k, to_v rows
+    bf16_t* O; int ldo;
+    const float* ln_g; const float* ln_b; float ln_eps;
+    int HW;                      // positions per frame (% 8 == 0); T = 16
+    float c;                     // scale * log2(e)
+};
+
+__global__ __launch_bounds__(256, 2)
+void ln_qkv_tattn320_kernel(const TaParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fr = lane & 31, fh = lane >> 5;
+    const unsigned lds_base = (unsigned)(unsigned long)((lds_char_t*)smem);
+    char* const vpatch = smem + 2 * LW_STAGE + wave * TA_PATCH;
+    float* const lns = reinterpret_cast<float*>(smem + 2 * LW_STAGE + 4 * TA_PATCH);
+    const int gpb = p.HW >> 3;                                    // 8-position groups per clip
+    const int b = (int)blockIdx.x / gpb, p0 = ((int)blockIdx.x - b * gpb) * 8 + 2 * wave;
+    auto grow = [&](int r) { return ((size_t)(b * 16 + (r & 15))) * p.HW + p0 + (r >> 4); };      // wave row r -> tensor row
+
+    unsigned vo[5];
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+        const int u = wave * 5 + i;
+        const int t = u >> 2, g = u & 3;
+        vo[i] = (unsigned)((g * 8 + (lane >> 3)) * (FD * 2) + t * 128 + (((lane & 7) ^ ((g * 4 + (lane >> 4)) & 7)) << 4));
+        asm volatile("" : "+v"(vo[i]));
+    }
+    auto dma_piece = [&](unsigned lds_dst, unsigned voff, uint64_t sbase) __attribute__((always_inline)) {
+        unsigned keep;
+        asm volatile(
+            "s_mov_b32 %0, m0\n\t"
+            "s_mov_b32 m0, %1\n\t"
+            "s_nop 0\n\t"
+            "global_load_lds_dwordx4 %2, %3\n\t"
+            "s_mov_b32 m0, %0"
+            : "=&s"(keep)
+            : "s"(lds_dst), "v"(voff), "s"(sbase)
+            : "memory");
+    };
+    // chunk (head h, part): part 0,1 = q halves, 2,3 = k halves, 4,5 = v halves -> weight rows (part/2) * 320 + 64 h + 32 (part&1)
+    auto w_base = [&](int h, int part) {
+        return (uint64_t)(uintptr_t)p.W + (uint64_t)((part >> 1) * FD + 64 * h + 32 * (part & 1)) * (FD * 2);
+    };
+    auto w_dst = [&](int slot, int i) { return lds_base + slot * LW_STAGE + (wave * 5 + i) * 1024; };
+
+#pragma unroll
+    for (int i = 0; i < 5; ++i) dma_piece(w_dst(0, i), vo[i], w_base(0, 0));
+
+    bf16x8_t xf[FD / 16];
+    {
+        const bf16_t* xr = p.X + grow(fr) * p.ldx + fh * 8;
+#pragma unroll
+        for (int kk = 0; kk < FD / 16; ++kk) xf[kk] = *reinterpret_cast<const bf16x8_t*>(xr + kk * 16);
+        for (int i = tid; i < FD; i += 256) { lns[i] = p.ln_g[i]; lns[FD + i] = p.ln_b[i]; }
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    ln_rows_inplace<FD>(xf, lns, lns + FD, p.ln_eps, fh);
+
+    constexpr int PD = 6;
+    int slot = 0;
+    const int li = lane & 15;
+    const int tr_off = (li >> 2) * TA_VLD + (((lane >> 4) & 1) * 16 + (li & 3) * 4) * 2;      // transposed v read (flash kernel)
+    const int px = fr >> 4;                                       // which of the wave's two positions this lane's row is
+    for (int h = 0; h < 5; ++h) {
+        bf16x8_t qf[4], kf[4];
+#pragma unroll
+        for (int part = 0; part < 6; ++part) {
+            if (h > 0 || part > 0) {
+                // this chunk's weights were issued during the previous chunk, in front of the 4 output stores of a head
+                if (part == 0) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+            }
+            const char* s1 = smem + slot * LW_STAGE;
+            f32x16_t acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+            bf16x8_t wr[PD];
+            auto rd = [&](int kk, int sl) __attribute__((always_inline)) {
+                wr[sl] = *(lds_vfrag_t*)((lds_char_t*)s1 + (kk >> 2) * 4096 + off128(fr, (kk & 3) * 2 + fh));
+            };
+#pragma unroll
+            for (int kk = 0; kk < PD; ++kk) rd(kk, kk);
+            const bool more = part < 5 || h < 4;
+            const uint64_t nb = part < 5 ? w_base(h, part + 1) : w_base(h + 1, 0);
+#pragma unroll
+            for (int kk = 0; kk < FD / 16; ++kk) {
+                bf16x8_t f = wr[kk % PD];
+                if (kk + PD < FD / 16) rd(kk + PD, kk % PD);
+                asm volatile("" : "+v"(f));
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f, xf[kk], acc, 0, 0, 0);
+                if (kk < 5 && more) dma_piece(w_dst(slot ^ 1, kk), vo[kk], nb);
+            }
+            slot ^= 1;
+            if (part < 4) {
+                // q / k block of this row: the two operand fragments of k steps 2 (part & 1), + 1
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    u32x4_t pw;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) pw[e] = pack_bf2(acc[8 * s2 + 2 * e], acc[8 * s2 + 2 * e + 1]);
+                    if (part < 2) qf[2 * (part & 1) + s2] = __builtin_bit_cast(bf16x8_t, pw);
+                    else kf[2 * (part & 1) + s2] = __builtin_bit_cast(bf16x8_t, pw);
+                }
+            } else {
+                // v block -> the wave's patch, row-major [frame row][64 d]: channels 8 q + 4 fh + i of half (part & 1)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    uint2 pk;
+                    pk.x = pack_bf2(acc[4 * q], acc[4 * q + 1]);
+                    pk.y = pack_bf2(acc[4 * q + 2], acc[4 * q + 3]);
+                    *reinterpret_cast<uint2*>(vpatch + fr * TA_VLD + (32 * (part & 1) + 8 * q + 4 * fh) * 2) = pk;
+                }
+            }
+        }
+        // ---- attention of head h over the 16 frames of each of the wave's two positions
+        f32x16_t sc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sc[r] = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[j], qf[j], sc, 0, 0, 0);
+        // lane = query row fr; sc[r] = score of key row n = (r & 3) + 8 (r >> 2) + 4 fh: the same position iff (r >> 3) == px
+        float mx = -1e30f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            if ((r >> 3) != px) sc[r] = -1e30f;
+            mx = fmaxf(mx, sc[r]);
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        float sum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            sc[r] = __builtin_amdgcn_exp2f((sc[r] - mx) * p.c);
+            sum += sc[r];
+        }
+        sum += __shfl_xor(sum, 32, 64);
+        const float inv = 1.0f / sum;
+        bf16x8_t pf[2];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            u32x4_t pw;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) pw[e] = pack_bf2(sc[8 * ks + 2 * e] * inv, sc[8 * ks + 2 * e + 1] * inv);
+            pf[ks] = __builtin_bit_cast(bf16x8_t, pw);
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);          // lgkmcnt(0): this wave's own v rows have landed in its patch
+        __builtin_amdgcn_wave_barrier();
+        f32x16_t oacc[2];
+#pragma unroll
+        for (int db = 0; db < 2; ++db) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) oacc[db][r] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const char* vp = vpatch + (16 * ks + 4 * fh) * TA_VLD + db * 64 + tr_off;
+                const bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_bf16x4_t*)(vp));
+                const bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_bf16x4_t*)(vp + 8 * TA_VLD));
+                bf16x8_t vf;
+                vf[0] = lo[0]; vf[1] = lo[1]; vf[2] = lo[2]; vf[3] = lo[3];
+                vf[4] = hi[0]; vf[5] = hi[1]; vf[6] = hi[2]; vf[7] = hi[3];
+                oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[ks], oacc[db], 0, 0, 0);
+            }
+        }
+        // ---- the head's 32 x 64 output block: bf16, row-major through the (now free) patch, 128-byte row segments
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                uint2 pk;
+                pk.x = pack_bf2(oacc[db][4 * q], oacc[db][4 * q + 1]);
+                pk.y = pack_bf2(oacc[db][4 * q + 2], oacc[db][4 * q + 3]);
+                *reinterpret_cast<uint2*>(vpatch + off128(fr, 4 * db + q) + fh * 8) = pk;
+            }
+        {
+            const int rrow = lane >> 3, rc = lane & 7;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int r = t * 8 + rrow;
+                const u32x4_t d = *reinterpret_cast<const u32x4_t*>(vpatch + off128(r, rc));
+                *reinterpret_cast<u32x4_t*>(p.O + grow(r) * p.ldo + 64 * h + rc * 8) = d;
+            }
+        }
+    }
+}
+
 }  // namespace
 
 #ifdef DC_FF_STAMPS
@@ -744,4 +956,25 @@ extern "C" int dc_gn_linear(const uint16_t* x, int ldx, int K, const float* gamm
     p.ln_g = gamma; p.ln_b = beta; p.ln_eps = 0.f;
     p.gn_stats = reinterpret_cast<const float2*>(stats); p.gn_groups = groups; p.gn_rpi = rows_per_inst;
     return launch_norm_linear(2, K, p, (hipStream_t)stream_);
+}
+
+extern "C" int dc_ln_qkv_temporal_attn320(const uint16_t* x, int ldx, const float* ln_gamma, const float* ln_beta, float ln_eps,
+                                          const uint16_t* wqkv, uint16_t* out, int ldo, int B, int T, int HW, float scale,
+                                          void* stream_) {
+    if (!x || !ln_gamma || !ln_beta || !wqkv || !out) return DC_ERR_ARG;
+    if (B < 1 || T != 16 || HW < 8 || HW % 8 || ldx % 8 || ldo % 8) return DC_ERR_SHAPE;
+    if (((uintptr_t)x | (uintptr_t)out | (uintptr_t)wqkv) % 16) return DC_ERR_SHAPE;
+    static bool configured = false;
+    if (!configured) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ln_qkv_tattn320_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, TA_LDS);
+        if (e != hipSuccess) return (int)e;
+        configured = true;
+    }
+    TaParams p;
+    p.X = x; p.ldx = ldx; p.W = wqkv; p.O = out; p.ldo = ldo; p.ln_g = ln_gamma; p.ln_b = ln_beta; p.ln_eps = ln_eps;
+    p.HW = HW; p.c = scale * 1.4426950408889634f;
+    hipLaunchKernelGGL(ln_qkv_tattn320_kernel, dim3((unsigned)(B * (HW / 8))), dim3(256), TA_LDS, (hipStream_t)stream_, p);
+    DC_CHECK_LAUNCH();
+    return 0;
 }

@@ -27,6 +27,7 @@ import os
 _BF16 = torch.bfloat16
 _FF_FUSED = os.environ.get("DC_FF_FUSED", "1") != "0"
 _LN_FUSED = os.environ.get("DC_LN_FUSED", "1") != "0"      # A/B switches of the fused kernels in ff_fused.hip
+_TA_FUSED = os.environ.get("DC_TA_FUSED", "1") != "0"
 _LN_FUSED_K = tuple(int(k) for k in os.environ.get("DC_LN_FUSED_K", "320,640").split(","))
 C_IN_PAD = 64   # conv_in consumes the 8 latent+concat channels zero-padded to one 64-wide K slice
 
@@ -420,8 +421,12 @@ class UNetModel(nn.Module):
     def _attn_self_temporal(self, Wa, ln, h, g, heads):
         A = self._arena
         M, dev, Cc = h.shape[0], h.device, heads * 64
-        qkv = self._ln_linear(h, ln, Wa["qkv"], A.get("qkv", M, 3 * Cc, device=dev))
         att = A.get("att", M, Cc, device=dev)
+        if _TA_FUSED and Cc == 320 and g["T"] == 16 and g["HW"] % 8 == 0 and M >= 32768:
+            # level 0: LayerNorm, q/k/v and the attention over the 16 frames in one kernel - no [M, 960] qkv tensor
+            ops.ln_qkv_temporal_attn320(h, ln, Wa["qkv"], att, B=g["B"], T=16, HW=g["HW"], scale=0.125)
+            return ops.gemm(att, Wa["out"], h, residual=h)
+        qkv = self._ln_linear(h, ln, Wa["qkv"], A.get("qkv", M, 3 * Cc, device=dev))
         ops.temporal_attn(qkv, att, B=g["B"], T=g["T"], HW=g["HW"], heads=heads, scale=0.125)
         return ops.gemm(att, Wa["out"], h, residual=h)
 

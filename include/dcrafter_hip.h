@@ -214,6 +214,15 @@ int dc_groupnorm_stats(const uint16_t* x, int ldx, int C, int groups, int n_inst
 int dc_gn_linear(const uint16_t* x, int ldx, int K, const float* gamma, const float* beta, const float* stats, int groups,
                  int rows_per_inst, const uint16_t* w, const float* bias, uint16_t* out, int ldo, int M, int N, void* stream);
 
+/* LayerNorm + to_q/k/v + attention over the T = 16 frames of every spatial position for dim 320 (5 heads x 64) in one launch:
+ * out[M, 320] = softmax_T(q k^T scale) v, [q | k | v] = LayerNorm(x) wqkv^T, rows ordered (clip, frame, position), M = B*16*HW,
+ * HW % 8 == 0. wqkv: bf16 [>= 960][320] (to_q, to_k, to_v rows). The qkv tensor never reaches HBM; bf16 roundings as in
+ * dc_layernorm -> dc_gemm_conv -> dc_temporal_attn_d64. out must not alias x.
+ * replaces TemporalTransformer's norm1 -> attn1 / norm2 -> attn2 up to (not including) to_out: lvdm/modules/attention.py:242-244
+ * (BasicTransformerBlock._forward) with CrossAttention.forward :101-125, at the UNet's level 0 */
+int dc_ln_qkv_temporal_attn320(const uint16_t* x, int ldx, const float* ln_gamma, const float* ln_beta, float ln_eps,
+                               const uint16_t* wqkv, uint16_t* out, int ldo, int B, int T, int HW, float scale, void* stream);
+
 /* ---- conditioning encoders (once per clip) ---------------------------------------------------- */
 
 /* Multi-head attention for any (even) head width d <= 256 and Lk <= 1024, optional causal mask (key j visible to query

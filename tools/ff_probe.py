@@ -47,3 +47,18 @@ for (Mr, K, N) in ((M, 320, 960), (M, 320, 320), (M // 4, 640, 1920), (M // 4, 6
         e1.record(); torch.cuda.synchronize()
         us = e0.elapsed_time(e1) / 10 * 1e3
         print(f"{name:10s} M={Mr} K={K} N={N}: {us:8.1f} us  {2.0 * Mr * N * K / us / 1e6:7.1f} TF/s  {2.0 * Mr * (K + N) / us / 1e6:6.2f} TB/s", flush=True)
+
+# LayerNorm + qkv + temporal attention in one kernel vs the three kernels (level 0: B = 2 clips, HW = 9216)
+Bc, T, HW = 2, 16, M // 32
+pwq = ops.PackedWeight.linear(torch.randn(960, 320, generator=g) * 320 ** -0.5, None, DEV)
+qkv = torch.empty(M, 960, dtype=torch.bfloat16, device=DEV); att = torch.empty(M, 320, dtype=torch.bfloat16, device=DEV)
+def three(): ops.ln_linear(h, pwq, qkv, ln=(gam, bet)); ops.temporal_attn(qkv, att, B=Bc, T=T, HW=HW, heads=5, scale=0.125)
+def fusedta(): ops.ln_qkv_temporal_attn320(h, (gam, bet), pwq, att, B=Bc, T=T, HW=HW, scale=0.125)
+for name, fn in (("ln_qkv+tattn", three), ("fused", fusedta), ("ln_qkv+tattn", three), ("fused", fusedta)):
+    for _ in range(2): fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(10): fn()
+    e1.record(); torch.cuda.synchronize()
+    print(f"{name:13s} M={M}: {e0.elapsed_time(e1) / 10 * 1e3:8.1f} us", flush=True)
