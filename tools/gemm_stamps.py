@@ -31,7 +31,7 @@ else:
     pw = PackedWeight.linear(torch.randn(co, ci) * ci ** -0.5, torch.randn(co), DEV)
     kw = {}
 o = torch.empty(M, co, dtype=torch.bfloat16, device=DEV)
-ws = ops._gemm_workspace(torch.device(DEV))
+ws = ops._gemm_workspace(torch.device(DEV), torch.cuda.current_stream().cuda_stream)
 for _ in range(3):
     ws.zero_()
     ops.gemm(x, pw, o, **kw)
