@@ -152,9 +152,12 @@ struct FfParams {
     const float* ln_g;           // optional LayerNorm in front (norm3 of BasicTransformerBlock): X is normalised in registers
     const float* ln_b;
     float ln_eps;
+    // optional Linear behind (the transformer's proj_out): y = R2 + (FeedForward result) Wp^T + bp; the FeedForward result is
+    // then NOT stored. Wp: [>= 320][320], k permuted inside every 32-chunk like W2p.
+    const bf16_t* Wp; const float* bp; const bf16_t* R2; int ldr2; bf16_t* O2; int ldo2;
 };
 
-template <bool LN>
+template <bool LN, bool PROJ>
 __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1)))
 void ff_geglu_fused320_kernel(const FfParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -245,7 +248,7 @@ void ff_geglu_fused320_kernel(const FfParams p) {
         // consumer passes through an empty volatile asm: that pins the distance. With plain loads hipcc sank each
         // read to just in front of its MFMA to save registers (window of one, `s_waitcnt lgkmcnt(0)` per MFMA pair),
         // and both MFMA phases ran at 64 cycles per MFMA instead of 32.
-        constexpr int PD = 4, PD2 = 8;
+        constexpr int PD = 4, PD2 = 6;
         // phase 1 of chunk c: value / gate pre-activations of its 32 channels for this wave's 32 rows
         auto phase1 = [&](int c, f32x16_t& av, f32x16_t& ag) __attribute__((always_inline)) {
             const char* s1 = w1s + (c & 1) * W1_STAGE;
@@ -292,12 +295,15 @@ void ff_geglu_fused320_kernel(const FfParams p) {
         };
         // phase 2 of chunk c (W2 ring stage st): out[row][ch] += P W2c^T (W2 packed in the matching k order). DW1 / DW2:
         // the wave's LDS-DMA pieces of W1(jd + 2) / W2(jd + 1) go out one behind each of the first MFMAs.
+        const int a2_0 = off64(fr, fh), a2_1 = off64(fr, 2 + fh);
         auto phase2 = [&](int st, const bf16x8_t (&pf)[2], auto DW1, auto DW2, int jd, int st_next) __attribute__((always_inline)) {
             const char* s2 = w2s + st * W2_STAGE;
             bf16x8_t w2r[PD2];
             auto rd2 = [&](int idx, int slot) __attribute__((always_inline)) {      // idx = s * 10 + nb
                 const int s = idx / (FD / 32), nb = idx % (FD / 32);
-                w2r[slot] = *(lds_vfrag_t*)((lds_char_t*)s2 + off64(nb * 32 + fr, s * 2 + fh));
+                // off64(nb * 32 + fr, s * 2 + fh) = nb * 2048 + (fr * 64 + swizzled chunk): nb only moves an immediate offset,
+                // two lane-dependent bases cover all 20 fragments (spelled out: hipcc kept 20 address registers otherwise)
+                w2r[slot] = *(lds_vfrag_t*)((lds_char_t*)s2 + (s ? a2_1 : a2_0) + nb * 2048);
             };
 #pragma unroll
             for (int i = 0; i < PD2; ++i) rd2(i, i);
@@ -334,9 +340,10 @@ void ff_geglu_fused320_kernel(const FfParams p) {
             };
 #pragma unroll
             for (int kk = 0; kk < PD; ++kk) rd1(kk, kk);
-            float4 bv, bg, bvn, bgn;                      // ff1 bias of the 4 channels in flight / of the next 4 (LDS latency)
-            bvn = *reinterpret_cast<const float4*>(b1s + c * FCH + 4 * fh);
-            bgn = *reinterpret_cast<const float4*>(b1s + FM + c * FCH + 4 * fh);
+            // ff1 bias of the 4 channels (quad q = kk / 4) in flight: the gate bias is last used at k step 4 q + 2, the value
+            // bias at 4 q + 3; each is reloaded right there for quad q + 1, two k steps ahead of its first use (LDS latency)
+            float4 bv = *reinterpret_cast<const float4*>(b1s + c * FCH + 4 * fh);
+            float4 bg = *reinterpret_cast<const float4*>(b1s + FM + c * FCH + 4 * fh);
             float xg0, xg1, ww0, ww1;
             u32x4_t pw[2];
 #pragma unroll
@@ -345,14 +352,6 @@ void ff_geglu_fused320_kernel(const FfParams p) {
                 if (kk + PD < FD / 16) rd1(kk + PD, kk % PD);
                 asm volatile("" : "+v"(fv), "+v"(fg));
                 const int m = kk >> 1;                    // channel pair (values 2m, 2m + 1 of the accumulators)
-                if (kk < 16 && (kk & 3) == 0) {           // accumulator values 4 q .. 4 q + 3 are channels 8 q + 4 fh + i, q = kk / 4
-                    bv = bvn; bg = bgn;
-                    if (kk < 12) {
-                        const int n = c * FCH + 8 * ((kk >> 2) + 1) + 4 * fh;
-                        bvn = *reinterpret_cast<const float4*>(b1s + n);
-                        bgn = *reinterpret_cast<const float4*>(b1s + FM + n);
-                    }
-                }
                 nv = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fv, xf[kk], nv, 0, 0, 0);
                 asm volatile("" : "+a"(nv));
                 // gelu(x) = x/2 (1 + erf(x/sqrt2)) with erf by Abramowitz-Stegun 7.1.26 (as erf_as_f), regrouped to
@@ -375,6 +374,8 @@ void ff_geglu_fused320_kernel(const FfParams p) {
                     ww0 = (q0 * t0) * fabsf(xg0);
                     ww1 = (q1 * t1) * fabsf(xg1);
                     asm volatile("" : "+v"(ww0), "+v"(ww1), "+v"(xg0), "+v"(xg1));
+                    if ((kk & 3) == 2 && kk < 12)         // accumulator values 4 q .. 4 q + 3 are channels 8 q + 4 fh + i
+                        bg = *reinterpret_cast<const float4*>(b1s + FM + c * FCH + 8 * ((kk >> 2) + 1) + 4 * fh);
                 } else if (kk < 16) {                     // exp half, GEGLU product, bf16 pack
                     float v0 = cv[2 * m], v1 = cv[2 * m + 1];
                     asm volatile("" : "+v"(v0), "+v"(v1));
@@ -390,6 +391,8 @@ void ff_geglu_fused320_kernel(const FfParams p) {
                     unsigned w = pack_bf2(o0, o1);
                     asm volatile("" : "+v"(w));
                     pw[m >> 2][m & 3] = w;
+                    if ((kk & 3) == 3 && kk < 12)
+                        bv = *reinterpret_cast<const float4*>(b1s + c * FCH + 8 * ((kk >> 2) + 1) + 4 * fh);
                 }
                 ng = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fg, xf[kk], ng, 0, 0, 0);
                 asm volatile("" : "+a"(ng));
@@ -447,40 +450,147 @@ void ff_geglu_fused320_kernel(const FfParams p) {
         st = st + 1 >= W2_RING ? 0 : st + 1;
         geglu(FNCH - 1, a1, a1g, pf);
         phase2(st, pf, no_t(), no_t(), 0, 0);
-        // ---- epilogue: + b2, bf16, + residual; row-major through the wave-private patch (32 rows x 64 B per block)
-        {
+        if constexpr (!PROJ) {
+            // ---- epilogue: + b2, bf16, + residual; row-major through the wave-private patch (32 rows x 64 B per block)
+            {
+                int lane_e = lane;
+                asm volatile("" : "+v"(lane_e));
+                const int fr_e = lane_e & 31, fh_e = lane_e >> 5;
+                const int rrow = lane_e >> 2, rc = lane_e & 3;
+#pragma unroll
+                for (int nb = 0; nb < FD / 32; ++nb) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int n = nb * 32 + 8 * q + 4 * fh_e;
+                        const float4 bv = *reinterpret_cast<const float4*>(p.b2 + n);
+                        uint2 pk;
+                        pk.x = pack_bf2(acc[nb][4 * q] + bv.x, acc[nb][4 * q + 1] + bv.y);
+                        pk.y = pack_bf2(acc[nb][4 * q + 2] + bv.z, acc[nb][4 * q + 3] + bv.w);
+                        *reinterpret_cast<uint2*>(ebuf + fr_e * 64 + (((2 * q + fh_e) ^ (((fr_e >> 1) & 3) << 1)) << 3)) = pk;
+                    }
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) {
+                        const int r = t * 16 + rrow;
+                        u32x4_t d = *reinterpret_cast<const u32x4_t*>(ebuf + r * 64 + ((rc ^ ((r >> 1) & 3)) << 4));
+                        const int m = m0 + r;
+                        if (m >= p.M) continue;
+                        const int n = nb * 32 + rc * 8;
+                        if (p.R) {
+                            const u32x4_t rr = *reinterpret_cast<const u32x4_t*>(p.R + (size_t)m * p.ldr + n);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e)
+                                d[e] = pack_bf2(__uint_as_float(d[e] << 16) + __uint_as_float(rr[e] << 16),
+                                                __uint_as_float(d[e] & 0xffff0000u) + __uint_as_float(rr[e] & 0xffff0000u));
+                        }
+                        *reinterpret_cast<u32x4_t*>(p.O + (size_t)m * p.ldo + n) = d;
+                    }
+                }
+            }
+        } else {
+            // ---- FeedForward result -> B fragments (bf16 where the stand-alone path rounds: acc + b2, then + residual), the
+            // transformer's proj_out behind it: y = R2 + h2 Wp^T + bp. A lane holds channels 8 q + 4 fh + i of each 32-block
+            // of ITS row, i.e. the two k-step fragments of that block in the k order Wp is packed in (as P feeds W2p).
             int lane_e = lane;
             asm volatile("" : "+v"(lane_e));
             const int fr_e = lane_e & 31, fh_e = lane_e >> 5;
-            const int rrow = lane_e >> 2, rc = lane_e & 3;
+            unsigned vo3[5];                             // pieces of a 32-row x 640-byte chunk of Wp (norm_linear's layout);
+#pragma unroll                                           // derived here from the opaque lane id: five more registers held
+            for (int i = 0; i < 5; ++i) {                // across the chunk loop spill
+                const int u = wave * 5 + i;
+                const int t = u >> 2, g = u & 3;
+                vo3[i] = (unsigned)((g * 8 + (lane_e >> 3)) * (FD * 2) + t * 128 + (((lane_e & 7) ^ ((g * 4 + (lane_e >> 4)) & 7)) << 4));
+            }
+            {
+                int mr = m0 + fr_e;
+                if (mr >= p.M) mr = p.M - 1;
+                const bf16_t* rrow = p.R + (size_t)mr * p.ldr + 4 * fh_e;
 #pragma unroll
-            for (int nb = 0; nb < FD / 32; ++nb) {
+                for (int nb = 0; nb < FD / 32; ++nb) {
+                    u32x4_t fw[2];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int n = nb * 32 + 8 * q;
+                        const float4 bv = *reinterpret_cast<const float4*>(p.b2 + n + 4 * fh_e);
+                        const uint2 rr = *reinterpret_cast<const uint2*>(rrow + n);
+                        const unsigned d0 = pack_bf2(acc[nb][4 * q] + bv.x, acc[nb][4 * q + 1] + bv.y);
+                        const unsigned d1 = pack_bf2(acc[nb][4 * q + 2] + bv.z, acc[nb][4 * q + 3] + bv.w);
+                        fw[q >> 1][2 * (q & 1)] = pack_bf2(__uint_as_float(d0 << 16) + __uint_as_float(rr.x << 16),
+                                                          __uint_as_float(d0 & 0xffff0000u) + __uint_as_float(rr.x & 0xffff0000u));
+                        fw[q >> 1][2 * (q & 1) + 1] = pack_bf2(__uint_as_float(d1 << 16) + __uint_as_float(rr.y << 16),
+                                                              __uint_as_float(d1 & 0xffff0000u) + __uint_as_float(rr.y & 0xffff0000u));
+                    }
+                    xf[2 * nb] = __builtin_bit_cast(bf16x8_t, fw[0]);
+                    xf[2 * nb + 1] = __builtin_bit_cast(bf16x8_t, fw[1]);
+                }
+            }
+            // Wp in chunks of 32 output channels (20 KB: 5 K tiles of [32 rows][128 B]) through two stages of the (idle) W2
+            // ring, 5 LDS-DMA pieces per wave, one chunk ahead; counted waits: a chunk's pieces are followed by the previous
+            // chunk's residual loads (2, already consumed) and stores (2)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();                // every wave is done reading the W rings of the FeedForward
+            asm volatile("" ::: "memory");
+            auto wp_base = [&](int c) { return (uint64_t)(uintptr_t)p.Wp + (uint64_t)c * (32 * FD * 2); };
+            auto wp_dst = [&](int c, int i) { return lds_base + 2 * W1_STAGE + (c & 1) * W2_STAGE + (wave * 5 + i) * 1024; };
+#pragma unroll
+            for (int i = 0; i < 5; ++i) dma_piece(wp_dst(0, i), vo3[i], wp_base(0));
+            const bool full_tile = tile * FBM + FBM <= p.M;
+            for (int c = 0; c < FD / 32; ++c) {
+                if (c == 0 || !full_tile) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+                const char* s3 = w2s + (c & 1) * W2_STAGE;
+                f32x16_t ya;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) ya[r] = 0.f;
+                constexpr int PD3 = 6;
+                bf16x8_t wr[PD3];
+                auto rd3 = [&](int kk, int sl) __attribute__((always_inline)) {
+                    wr[sl] = *(lds_vfrag_t*)((lds_char_t*)s3 + (kk >> 2) * 4096 + off128(fr_e, (kk & 3) * 2 + fh_e));
+                };
+#pragma unroll
+                for (int kk = 0; kk < PD3; ++kk) rd3(kk, kk);
+                const bool more = c + 1 < FD / 32;
+                const uint64_t nbase = wp_base(c + 1);
+#pragma unroll
+                for (int kk = 0; kk < FD / 16; ++kk) {
+                    bf16x8_t f = wr[kk % PD3];
+                    if (kk + PD3 < FD / 16) rd3(kk + PD3, kk % PD3);
+                    asm volatile("" : "+v"(f));
+                    ya = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f, xf[kk], ya, 0, 0, 0);
+                    if (kk < 5 && more) dma_piece(wp_dst(c + 1, kk), vo3[kk], nbase);
+                }
+                // chunk epilogue: + bp, bf16, + R2, row-major through the wave-private patch (32 rows x 64 B)
+                const int n0 = c * 32;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const int n = nb * 32 + 8 * q + 4 * fh_e;
-                    const float4 bv = *reinterpret_cast<const float4*>(p.b2 + n);
+                    const float4 bv = *reinterpret_cast<const float4*>(p.bp + n0 + 8 * q + 4 * fh_e);
                     uint2 pk;
-                    pk.x = pack_bf2(acc[nb][4 * q] + bv.x, acc[nb][4 * q + 1] + bv.y);
-                    pk.y = pack_bf2(acc[nb][4 * q + 2] + bv.z, acc[nb][4 * q + 3] + bv.w);
+                    pk.x = pack_bf2(ya[4 * q] + bv.x, ya[4 * q + 1] + bv.y);
+                    pk.y = pack_bf2(ya[4 * q + 2] + bv.z, ya[4 * q + 3] + bv.w);
                     *reinterpret_cast<uint2*>(ebuf + fr_e * 64 + (((2 * q + fh_e) ^ (((fr_e >> 1) & 3) << 1)) << 3)) = pk;
+                }
+                const int rrow2 = lane_e >> 2, rc = lane_e & 3;
+                u32x4_t rres[2];
+                int mrow[2];
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    mrow[t] = m0 + t * 16 + rrow2;
+                    const int mc = mrow[t] < p.M ? mrow[t] : p.M - 1;
+                    rres[t] = *reinterpret_cast<const u32x4_t*>(p.R2 + (size_t)mc * p.ldr2 + n0 + rc * 8);
                 }
 #pragma unroll
                 for (int t = 0; t < 2; ++t) {
-                    const int r = t * 16 + rrow;
+                    const int r = t * 16 + rrow2;
                     u32x4_t d = *reinterpret_cast<const u32x4_t*>(ebuf + r * 64 + ((rc ^ ((r >> 1) & 3)) << 4));
-                    const int m = m0 + r;
-                    if (m >= p.M) continue;
-                    const int n = nb * 32 + rc * 8;
-                    if (p.R) {
-                        const u32x4_t rr = *reinterpret_cast<const u32x4_t*>(p.R + (size_t)m * p.ldr + n);
 #pragma unroll
-                        for (int e = 0; e < 4; ++e)
-                            d[e] = pack_bf2(__uint_as_float(d[e] << 16) + __uint_as_float(rr[e] << 16),
-                                            __uint_as_float(d[e] & 0xffff0000u) + __uint_as_float(rr[e] & 0xffff0000u));
-                    }
-                    *reinterpret_cast<u32x4_t*>(p.O + (size_t)m * p.ldo + n) = d;
+                    for (int e = 0; e < 4; ++e)
+                        d[e] = pack_bf2(__uint_as_float(d[e] << 16) + __uint_as_float(rres[t][e] << 16),
+                                        __uint_as_float(d[e] & 0xffff0000u) + __uint_as_float(rres[t][e] & 0xffff0000u));
+                    if (mrow[t] < p.M) *reinterpret_cast<u32x4_t*>(p.O2 + (size_t)mrow[t] * p.ldo2 + n0 + rc * 8) = d;
                 }
             }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
     }
 #ifdef DC_FF_STAMPS
@@ -876,31 +986,54 @@ extern "C" int dc_ff_debug_stamps(unsigned long long* out, int reset) {
 }
 #endif
 
+template <bool LN, bool PROJ>
+static int launch_ff_fused(const FfParams& p, hipStream_t stream) {
+    static bool configured = false;
+    if (!configured) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ff_geglu_fused320_kernel<LN, PROJ>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, FF_LDS);
+        if (e != hipSuccess) return (int)e;
+        configured = true;
+    }
+    const int tiles = (p.M + FBM - 1) / FBM;
+    hipLaunchKernelGGL((ff_geglu_fused320_kernel<LN, PROJ>), dim3(tiles < 256 ? tiles : 256), dim3(256), FF_LDS, stream, p);
+    DC_CHECK_LAUNCH();
+    return 0;
+}
+
+static int ff_fused_common(const uint16_t* x, int ldx, const float* ln_gamma, const float* ln_beta, float ln_eps,
+                           const uint16_t* w1, const float* b1, const uint16_t* w2p, const float* b2, const uint16_t* residual,
+                           int ldr, uint16_t* out, int ldo, const uint16_t* wp, const float* bp, const uint16_t* residual2,
+                           int ldr2, uint16_t* out2, int ldo2, int M, hipStream_t stream) {
+    FfParams p;
+    p.X = x; p.ldx = ldx; p.W1 = w1; p.b1 = b1; p.W2p = w2p; p.b2 = b2; p.R = residual; p.ldr = ldr; p.O = out; p.ldo = ldo;
+    p.M = M; p.ln_g = ln_gamma; p.ln_b = ln_beta; p.ln_eps = ln_eps;
+    p.Wp = wp; p.bp = bp; p.R2 = residual2; p.ldr2 = ldr2; p.O2 = out2; p.ldo2 = ldo2;
+    if (wp) return ln_gamma ? launch_ff_fused<true, true>(p, stream) : launch_ff_fused<false, true>(p, stream);
+    return ln_gamma ? launch_ff_fused<true, false>(p, stream) : launch_ff_fused<false, false>(p, stream);
+}
+
 extern "C" int dc_ff_geglu_fused320(const uint16_t* x, int ldx, const float* ln_gamma, const float* ln_beta, float ln_eps,
                                     const uint16_t* w1, const float* b1, const uint16_t* w2p, const float* b2,
                                     const uint16_t* residual, int ldr, uint16_t* out, int ldo, int M, void* stream_) {
     if (!x || !w1 || !b1 || !w2p || !b2 || !out || ((ln_gamma == nullptr) != (ln_beta == nullptr))) return DC_ERR_ARG;
     if (M < 1 || ldx % 8 || ldo % 8 || (residual && ldr % 8)) return DC_ERR_SHAPE;
     if (((uintptr_t)x | (uintptr_t)out | (uintptr_t)w1 | (uintptr_t)w2p | (uintptr_t)(residual ? residual : out)) % 16) return DC_ERR_SHAPE;
-    static bool configured = false;
-    if (!configured) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ff_geglu_fused320_kernel<false>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, FF_LDS);
-        if (e == hipSuccess)
-            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ff_geglu_fused320_kernel<true>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, FF_LDS);
-        if (e != hipSuccess) return (int)e;
-        configured = true;
-    }
-    FfParams p;
-    p.X = x; p.ldx = ldx; p.W1 = w1; p.b1 = b1; p.W2p = w2p; p.b2 = b2; p.R = residual; p.ldr = ldr; p.O = out; p.ldo = ldo;
-    p.M = M; p.ln_g = ln_gamma; p.ln_b = ln_beta; p.ln_eps = ln_eps;
-    const int tiles = (M + FBM - 1) / FBM;
-    const dim3 grid(tiles < 256 ? tiles : 256);
-    if (ln_gamma) hipLaunchKernelGGL(ff_geglu_fused320_kernel<true>, grid, dim3(256), FF_LDS, (hipStream_t)stream_, p);
-    else hipLaunchKernelGGL(ff_geglu_fused320_kernel<false>, grid, dim3(256), FF_LDS, (hipStream_t)stream_, p);
-    DC_CHECK_LAUNCH();
-    return 0;
+    return ff_fused_common(x, ldx, ln_gamma, ln_beta, ln_eps, w1, b1, w2p, b2, residual, ldr, out, ldo, nullptr, nullptr,
+                           nullptr, 0, nullptr, 0, M, (hipStream_t)stream_);
+}
+
+extern "C" int dc_ff_geglu_proj_fused320(const uint16_t* x, int ldx, const float* ln_gamma, const float* ln_beta, float ln_eps,
+                                         const uint16_t* w1, const float* b1, const uint16_t* w2p, const float* b2,
+                                         const uint16_t* wp, const float* bp, const uint16_t* residual2, int ldr2,
+                                         uint16_t* out, int ldo, int M, void* stream_) {
+    if (!x || !w1 || !b1 || !w2p || !b2 || !wp || !bp || !residual2 || !out || ((ln_gamma == nullptr) != (ln_beta == nullptr)))
+        return DC_ERR_ARG;
+    if (M < 1 || ldx % 8 || ldo % 8 || ldr2 % 8) return DC_ERR_SHAPE;
+    if (((uintptr_t)x | (uintptr_t)out | (uintptr_t)w1 | (uintptr_t)w2p | (uintptr_t)wp | (uintptr_t)residual2) % 16) return DC_ERR_SHAPE;
+    // the FeedForward's own residual is its input x
+    return ff_fused_common(x, ldx, ln_gamma, ln_beta, ln_eps, w1, b1, w2p, b2, x, ldx, nullptr, 0, wp, bp, residual2, ldr2, out,
+                           ldo, M, (hipStream_t)stream_);
 }
 
 template <int NORM, int KH>

@@ -28,6 +28,7 @@ _BF16 = torch.bfloat16
 _FF_FUSED = os.environ.get("DC_FF_FUSED", "1") != "0"
 _LN_FUSED = os.environ.get("DC_LN_FUSED", "1") != "0"      # A/B switches of the fused kernels in ff_fused.hip
 _TA_FUSED = os.environ.get("DC_TA_FUSED", "1") != "0"
+_FFP_FUSED = os.environ.get("DC_FFP_FUSED", "1") != "0"
 _LN_FUSED_K = tuple(int(k) for k in os.environ.get("DC_LN_FUSED_K", "320,640").split(","))
 C_IN_PAD = 64   # conv_in consumes the 8 latent+concat channels zero-padded to one 64-wide K slice
 
@@ -299,9 +300,16 @@ class UNetModel(nn.Module):
                 d["attn2"] = attn_self(p + ".attn2")
             return d
 
+        def with_projp(d, p):
+            # dim 320: proj_out in the k order of the fused FeedForward + proj_out kernel (ops.ff_geglu_proj_fused320)
+            w = self._p(p + ".proj_out.weight")
+            if "ff2p" in d["blk"] and w.shape[0] == 320 and w[0].numel() == 320:
+                d["proj_p"] = ops.ff2_permuted(w.reshape(320, 320), device)
+            return d
+
         def temporal(p):
-            return {"norm": (f32(p + ".norm.weight"), f32(p + ".norm.bias")), "proj_in": lin(p + ".proj_in"),
-                    "blk": tblock(p + ".transformer_blocks.0", False), "proj_out": lin(p + ".proj_out")}
+            return with_projp({"norm": (f32(p + ".norm.weight"), f32(p + ".norm.bias")), "proj_in": lin(p + ".proj_in"),
+                               "blk": tblock(p + ".transformer_blocks.0", False), "proj_out": lin(p + ".proj_out")}, p)
 
         P["time0"], P["time2"] = lin("time_embed.0"), lin("time_embed.2")
         if self.fs_condition:
@@ -331,8 +339,8 @@ class UNetModel(nn.Module):
                                             PackedWeight.tconv3(self._p(f"{q}.{ci}.weight"), self._p(f"{q}.{ci}.bias"), device)))
                     out.append(d)
                 elif kind == "spatial":
-                    out.append({"norm": (f32(p + ".norm.weight"), f32(p + ".norm.bias")), "proj_in": lin(p + ".proj_in"),
-                                "blk": tblock(p + ".transformer_blocks.0", True), "proj_out": lin(p + ".proj_out")})
+                    out.append(with_projp({"norm": (f32(p + ".norm.weight"), f32(p + ".norm.bias")), "proj_in": lin(p + ".proj_in"),
+                                           "blk": tblock(p + ".transformer_blocks.0", True), "proj_out": lin(p + ".proj_out")}, p))
                 elif kind == "temporal":
                     out.append(temporal(p))
                 elif kind == "down":
@@ -440,6 +448,15 @@ class UNetModel(nn.Module):
         mid = ops.gemm(n, Wb["ff1"], A.get("ffmid", h.shape[0], Wb["ff1"].N // 2, device=h.device), geglu=True)
         return ops.gemm(mid, Wb["ff2"], h, residual=h)
 
+    def _ff_proj(self, W, h, x, out):
+        """the tail of a transformer: h = h + ff(norm3(h)); return x + proj_out(h) - one kernel at dim 320 / level-0 rows"""
+        B_ = W["blk"]
+        if "proj_p" in W and _FF_FUSED and _FFP_FUSED and h.shape[0] >= 32768:
+            return ops.ff_geglu_proj_fused320(h, B_["ff1"], B_["ff2p"], B_["ff2"].bias, W["proj_p"], W["proj_out"].bias, x, out,
+                                              ln=B_["norm3"], ln_eps=1e-5)
+        h = self._ff(B_, h)
+        return ops.gemm(h, W["proj_out"], out, residual=x)
+
     def _spatial_pre(self, W, x, g, heads):
         """SpatialTransformer up to and including the self-attention residual: everything that does not see the
         context (identical for all guidance branches of one latent)."""
@@ -486,8 +503,7 @@ class UNetModel(nn.Module):
             ops.flash_attn(q, kv[:, :Cc], kv[:, Cc:2 * Cc], att, batch=g["F"], heads=heads, Lq=g["HW"], Lk=nt, scale=0.125,
                            kv_bstride=Lc)
         h = ops.gemm(att, B_["out2"], h, residual=h)
-        h = self._ff(B_, h)
-        return ops.gemm(h, W["proj_out"], out if out is not None else A.get(out_tag, M, Cc, device=dev), residual=x)
+        return self._ff_proj(W, h, x, out if out is not None else A.get(out_tag, M, Cc, device=dev))
 
     def _spatial(self, W, x, g, heads, out_tag, out=None):
         return self._spatial_post(W, x, self._spatial_pre(W, x, g, heads), g, heads, out_tag, out=out)
@@ -501,8 +517,7 @@ class UNetModel(nn.Module):
         B_ = W["blk"]
         h = self._attn_self_temporal(B_["attn1"], B_["norm1"], h, g, heads)
         h = self._attn_self_temporal(B_["attn2"], B_["norm2"], h, g, heads)
-        h = self._ff(B_, h)
-        return ops.gemm(h, W["proj_out"], out if out is not None else A.get(out_tag, M, Cc, device=dev), residual=x)
+        return self._ff_proj(W, h, x, out if out is not None else A.get(out_tag, M, Cc, device=dev))
 
     def _run_block(self, blk, Wb, h, g, tag, final=None):
         """`final(rows, cols)` -> the tensor the LAST layer of the block must write (a column range of a skip-concat

@@ -422,6 +422,28 @@ def ff_geglu_fused320(x, pw1, w2p, b2, out, residual=None, ln=None, ln_eps=1e-5)
     return out
 
 
+def ff_geglu_proj_fused320(x, pw1, w2p, b2, wp, bp, residual2, out, ln=None, ln_eps=1e-5):
+    """out = residual2 + Linear_p(x + FeedForward_GEGLU(LayerNorm(x) if ln else x)) for dim 320 in one launch (the last two
+    steps of a transformer: FeedForward with its residual, proj_out with the transformer's residual); wp =
+    ff2_permuted(proj_out.weight)."""
+    _rows(x, "x"); _rows(out, "out"); _rows(residual2, "residual2")
+    M = x.shape[0]
+    if pw1.K != 320 or pw1.N != 2560 or pw1.bias is None or tuple(w2p.shape[1:]) != (1280,) or w2p.shape[0] < 320 \
+            or tuple(wp.shape[1:]) != (320,) or wp.shape[0] < 320:
+        raise ValueError("ff_geglu_proj_fused320: dim must be 320 (ff1 [2560, 320] with bias, ff2 [320, 1280], proj [320, 320])")
+    if x.data_ptr() == out.data_ptr():
+        raise ValueError("ff_geglu_proj_fused320: out must not alias x")
+    _need_rows(x, M, 320, "x"); _need_rows(out, M, 320, "out"); _need_rows(residual2, M, 320, "residual2")
+    _need(b2, 320, "b2"); _need(bp, 320, "bp")
+    if ln is not None:
+        _need(ln[0], 320, "ln gamma"); _need(ln[1], 320, "ln beta")
+    _launch("ff_geglu_proj_fused320", 2.0 * M * (2560 + 1280 + 320) * 320, 2.0 * M * 320 * 3 + 2.0 * (2560 * 320 + 320 * 1280 + 320 * 320),
+            _hip.lib().dc_ff_geglu_proj_fused320, _ptr(x), x.stride(0), _ptr(None if ln is None else ln[0]),
+            _ptr(None if ln is None else ln[1]), ln_eps, _ptr(pw1.w), _ptr(pw1.bias), _ptr(w2p), _ptr(b2), _ptr(wp), _ptr(bp),
+            _ptr(residual2), residual2.stride(0), _ptr(out), out.stride(0), M, stream_ptr())
+    return out
+
+
 def ln_linear(x, pw, out, ln=None, ln_eps=1e-5):
     """out = Linear(LayerNorm(x) if ln else x) for dim 320 / 640 in one launch; pw = PackedWeight.linear (N % 32 == 0);
     ln = (gamma, beta) fp32 or None."""

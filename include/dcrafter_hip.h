@@ -196,6 +196,15 @@ int dc_ff_geglu_fused320(const uint16_t* x, int ldx, const float* ln_gamma, cons
                          const uint16_t* w1, const float* b1, const uint16_t* w2p, const float* b2, const uint16_t* residual,
                          int ldr, uint16_t* out, int ldo, int M, void* stream);
 
+/* dc_ff_geglu_fused320 with the transformer's proj_out behind it: out = residual2 + h2 wp^T + bp, h2 = x + FeedForward(norm3(x))
+ * (h2 itself is not stored). wp: proj_out.weight bf16 [>= 320][320] with the k order of w2p inside every 32-chunk; bp fp32
+ * [320]; residual2 (the transformer's input) / out: bf16 rows; out may alias residual2 but not x.
+ * replaces BasicTransformerBlock._forward :246 + SpatialTransformer.forward :307-310 / TemporalTransformer.forward :404-412
+ * (proj_out and the `+ x_in`) of lvdm/modules/attention.py at the UNet's level 0 */
+int dc_ff_geglu_proj_fused320(const uint16_t* x, int ldx, const float* ln_gamma, const float* ln_beta, float ln_eps,
+                              const uint16_t* w1, const float* b1, const uint16_t* w2p, const float* b2, const uint16_t* wp,
+                              const float* bp, const uint16_t* residual2, int ldr2, uint16_t* out, int ldo, int M, void* stream);
+
 /* Norm + Linear for dim K = 320 or 640: out[M,N] = n W^T (+ bias), N % 32 == 0; x/out: bf16 rows (ld % 8 == 0, 16-byte
  * aligned); w: bf16 [>= N][K] as dc_gemm_conv takes a Linear weight; bias fp32 [N] or NULL. The normalised rows live in
  * registers only (rounded to bf16 where dc_layernorm / dc_groupnorm round their outputs).

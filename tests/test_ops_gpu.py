@@ -770,3 +770,16 @@ def test_ff_geglu_fused320_vs_torch(ops, M):
     ops.ff_geglu_fused320(n_ref, pw1, w2p, pw2.bias, want, residual=h)
     ops.ff_geglu_fused320(h, pw1, w2p, pw2.bias, h, residual=h, ln=(gam.to(DEV), bet.to(DEV)))
     assert rel_l2(h, want) < 2e-3                      # same rounding points; the row statistics sum in a different order
+    # with the transformer's proj_out (+ its residual) behind: y = r2 + proj(x + ff(LN(x)))
+    wp = torch.randn(320, 320, generator=g) * 320 ** -0.5; bp = torch.randn(320, generator=g) * 0.1
+    pwp = ops.PackedWeight.linear(wp, bp, DEV)
+    r2 = torch.randn(M, 320, generator=g).to(torch.bfloat16).to(DEV)
+    y_want = torch.empty_like(want)
+    ops.gemm(want, pwp, y_want, residual=r2)
+    h0 = (x * 1.7 + 0.3).to(torch.bfloat16).to(DEV)
+    y = torch.empty_like(h0)
+    ops.ff_geglu_proj_fused320(h0, pw1, w2p, pw2.bias, ops.ff2_permuted(wp, DEV), pwp.bias, r2, y, ln=(gam.to(DEV), bet.to(DEV)))
+    assert rel_l2(y, y_want) < 3e-3
+    y2 = r2.clone()                                     # in place on the transformer's input buffer
+    ops.ff_geglu_proj_fused320(h0, pw1, w2p, pw2.bias, ops.ff2_permuted(wp, DEV), pwp.bias, y2, y2, ln=(gam.to(DEV), bet.to(DEV)))
+    assert torch.equal(y2, y)
