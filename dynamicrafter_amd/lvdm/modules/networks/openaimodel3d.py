@@ -29,6 +29,7 @@ _FF_FUSED = os.environ.get("DC_FF_FUSED", "1") != "0"
 _LN_FUSED = os.environ.get("DC_LN_FUSED", "1") != "0"      # A/B switches of the fused kernels in ff_fused.hip
 _TA_FUSED = os.environ.get("DC_TA_FUSED", "1") != "0"
 _FFP_FUSED = os.environ.get("DC_FFP_FUSED", "1") != "0"
+_FUSED_MIN_ROWS = int(os.environ.get("DC_FUSED_MIN_ROWS", "32768"))     # below this the tile GEMMs + norm kernels are used
 _LN_FUSED_K = tuple(int(k) for k in os.environ.get("DC_LN_FUSED_K", "320,640").split(","))
 C_IN_PAD = 64   # conv_in consumes the 8 latent+concat channels zero-padded to one 64-wide K slice
 
@@ -404,14 +405,14 @@ class UNetModel(nn.Module):
     def _ln_linear(self, h, ln, pw, out):
         """Linear(LayerNorm(h)): at dim 320 / 640 and level-0 / level-1 row counts one kernel with the LayerNorm in registers (the
         normalised copy never reaches HBM), otherwise LayerNorm kernel + GEMM."""
-        if _LN_FUSED and pw.K in _LN_FUSED_K and pw.N % 32 == 0 and h.shape[0] >= 32768:
+        if _LN_FUSED and pw.K in _LN_FUSED_K and pw.N % 32 == 0 and h.shape[0] >= _FUSED_MIN_ROWS:
             return ops.ln_linear(h, pw, out, ln=ln, ln_eps=1e-5)
         return ops.gemm(self._ln(h, ln, "ln"), pw, out)
 
     def _gn_linear(self, x, gnw, pw, out, *, n_inst, rpi):
         """Linear(GroupNorm(x)) (eps 1e-6, no activation: the transformers' norm -> proj_in): at dim 320 / 640 and level-0 / level-1
         row counts the statistics pass plus one kernel that normalises in registers, otherwise GroupNorm + GEMM."""
-        if _LN_FUSED and pw.K in _LN_FUSED_K and pw.N % 32 == 0 and x.shape[0] >= 32768 and rpi % 128 == 0:
+        if _LN_FUSED and pw.K in _LN_FUSED_K and pw.N % 32 == 0 and x.shape[0] >= _FUSED_MIN_ROWS and rpi % 128 == 0:
             st = self._arena.get("gn_stats", n_inst * 32 * 2, 1, torch.float32, x.device)
             ops.groupnorm_stats(x, st, groups=32, n_inst=n_inst, rows_per_inst=rpi, eps=1e-6)
             return ops.gn_linear(x, gnw[0], gnw[1], st, pw, out, groups=32, rows_per_inst=rpi)
@@ -430,7 +431,7 @@ class UNetModel(nn.Module):
         A = self._arena
         M, dev, Cc = h.shape[0], h.device, heads * 64
         att = A.get("att", M, Cc, device=dev)
-        if _TA_FUSED and Cc == 320 and g["T"] == 16 and g["HW"] % 8 == 0 and M >= 32768:
+        if _TA_FUSED and Cc == 320 and g["T"] == 16 and g["HW"] % 8 == 0 and M >= _FUSED_MIN_ROWS:
             # level 0: LayerNorm, q/k/v and the attention over the 16 frames in one kernel - no [M, 960] qkv tensor
             ops.ln_qkv_temporal_attn320(h, ln, Wa["qkv"], att, B=g["B"], T=16, HW=g["HW"], scale=0.125)
             return ops.gemm(att, Wa["out"], h, residual=h)
@@ -440,7 +441,7 @@ class UNetModel(nn.Module):
 
     def _ff(self, Wb, h, tag="ln"):
         A = self._arena
-        if "ff2p" in Wb and _FF_FUSED and h.shape[0] >= 32768:
+        if "ff2p" in Wb and _FF_FUSED and h.shape[0] >= _FUSED_MIN_ROWS:
             # dim 320: x = ff(norm3(x)) + x in ONE kernel - LayerNorm in registers, ff1 -> GEGLU -> ff2, residual add; the
             # normalised copy and the [rows, 1280] intermediate never reach HBM
             return ops.ff_geglu_fused320(h, Wb["ff1"], Wb["ff2p"], Wb["ff2"].bias, h, residual=h, ln=Wb["norm3"], ln_eps=1e-5)
@@ -451,7 +452,7 @@ class UNetModel(nn.Module):
     def _ff_proj(self, W, h, x, out):
         """the tail of a transformer: h = h + ff(norm3(h)); return x + proj_out(h) - one kernel at dim 320 / level-0 rows"""
         B_ = W["blk"]
-        if "proj_p" in W and _FF_FUSED and _FFP_FUSED and h.shape[0] >= 32768:
+        if "proj_p" in W and _FF_FUSED and _FFP_FUSED and h.shape[0] >= _FUSED_MIN_ROWS:
             return ops.ff_geglu_proj_fused320(h, B_["ff1"], B_["ff2p"], B_["ff2"].bias, W["proj_p"], W["proj_out"].bias, x, out,
                                               ln=B_["norm3"], ln_eps=1e-5)
         h = self._ff(B_, h)
