@@ -121,7 +121,7 @@ __device__ __forceinline__ void ln_rows_inplace(bf16x8_t (&xf)[KD / 16], const f
 
 // x * a[c] + b[c] on the rows held as X fragments (GroupNorm with the statistics already known: a = gamma rstd,
 // b = beta - mean a, the arithmetic of gn_apply_kernel in norms.hip), rounded to bf16 like that kernel's output
-template <int KD>
+template <int KD, bool SILU = false>
 __device__ __forceinline__ void affine_rows_inplace(bf16x8_t (&xf)[KD / 16], const float* a, const float* b, int fh) {
 #pragma unroll
     for (int kk = 0; kk < KD / 16; ++kk) {
@@ -130,11 +130,17 @@ __device__ __forceinline__ void affine_rows_inplace(bf16x8_t (&xf)[KD / 16], con
         const int c0 = kk * 16 + fh * 8;
         const float4 g0 = *reinterpret_cast<const float4*>(a + c0), g1 = *reinterpret_cast<const float4*>(a + c0 + 4);
         const float4 b0 = *reinterpret_cast<const float4*>(b + c0), b1 = *reinterpret_cast<const float4*>(b + c0 + 4);
+        float v[8] = {__uint_as_float(w[0] << 16) * g0.x + b0.x, __uint_as_float(w[0] & 0xffff0000u) * g0.y + b0.y,
+                      __uint_as_float(w[1] << 16) * g0.z + b0.z, __uint_as_float(w[1] & 0xffff0000u) * g0.w + b0.w,
+                      __uint_as_float(w[2] << 16) * g1.x + b1.x, __uint_as_float(w[2] & 0xffff0000u) * g1.y + b1.y,
+                      __uint_as_float(w[3] << 16) * g1.z + b1.z, __uint_as_float(w[3] & 0xffff0000u) * g1.w + b1.w};
+        if constexpr (SILU) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = silu_f(v[e]);
+        }
         u32x4_t o;
-        o[0] = pack_bf2(__uint_as_float(w[0] << 16) * g0.x + b0.x, __uint_as_float(w[0] & 0xffff0000u) * g0.y + b0.y);
-        o[1] = pack_bf2(__uint_as_float(w[1] << 16) * g0.z + b0.z, __uint_as_float(w[1] & 0xffff0000u) * g0.w + b0.w);
-        o[2] = pack_bf2(__uint_as_float(w[2] << 16) * g1.x + b1.x, __uint_as_float(w[2] & 0xffff0000u) * g1.y + b1.y);
-        o[3] = pack_bf2(__uint_as_float(w[3] << 16) * g1.z + b1.z, __uint_as_float(w[3] & 0xffff0000u) * g1.w + b1.w);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = pack_bf2(v[2 * e], v[2 * e + 1]);
         xf[kk] = __builtin_bit_cast(bf16x8_t, o);
         asm volatile("" : "+v"(xf[kk]));
     }
@@ -973,6 +979,164 @@ void ln_qkv_tattn320_kernel(const TaParams p) {
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// GroupNorm (known statistics) + SiLU + temporal convolution (3,1,1) (+ residual) for 320 channels in ONE launch:
+//   out[b, f, p, :] = bias + sum_t W_t a[b, f + t - 1, p, :] (zero outside the clip),  a = silu(GroupNorm(x))
+//   reference: TemporalConvBlock lvdm/modules/networks/openaimodel3d.py:239-279 (conv1..conv4 = GroupNorm(32) -> SiLU ->
+//   Conv3d (3,1,1), zero padding in time); the block's `identity + x` (:279) rides on the last conv as `residual`.
+// As GroupNorm (statistics, apply) + implicit GEMM the activated copy is written, then read three times (once per tap)
+// through the L2. Here the rows are gathered as in ln_qkv_tattn320_kernel: a wave owns 2 positions x 16 frames, so the
+// frames f - 1 and f + 1 of a row are its NEIGHBOUR LANES. The normalised, activated X fragments stay in registers; per
+// 32-column chunk three products Y_t = X W_t^T (the same X, 20 MFMAs each) and
+//   out[f] = Y_0[f - 1] + Y_1[f] + Y_2[f + 1]
+// is two DPP row shifts (16-lane rows = the 16 frames of a position; the shifted-in lane is 0 = the zero padding).
+struct TcParams {
+    const bf16_t* X; int ldx;
+    const bf16_t* W;             // PackedWeight.tconv3: [>= N][960], k = (64-channel slice, tap, channel in slice)
+    const float* bias;           // [N]
+    const bf16_t* R; int ldr;    // residual rows or nullptr
+    bf16_t* O; int ldo;
+    const float* gn_g; const float* gn_b; const float2* gn_stats; int gn_groups;      // stats [clip][group] = (mean, rstd)
+    int HW, N;
+};
+
+template <bool RES>
+__global__ __launch_bounds__(256, 2)
+void gn_silu_tconv320_kernel(const TcParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fr = lane & 31, fh = lane >> 5;
+    const unsigned lds_base = (unsigned)(unsigned long)((lds_char_t*)smem);
+    char* const ebuf = smem + 2 * LW_STAGE + wave * 2048;
+    float* const lns = reinterpret_cast<float*>(smem + 2 * LW_STAGE + 4 * 2048);
+    const int gpb = p.HW >> 3;
+    const int b = (int)blockIdx.x / gpb, p0 = ((int)blockIdx.x - b * gpb) * 8 + 2 * wave;
+    auto grow = [&](int r) { return ((size_t)(b * 16 + (r & 15))) * p.HW + p0 + (r >> 4); };      // wave row r -> tensor row
+
+    // LDS-DMA of stage (chunk c, tap t): 32 weight rows x the tap's 320 channels = 5 K tiles of [32 rows][128 B]; in the
+    // packed weight a K tile (64-channel slice s) of tap t starts at column 192 s + 64 t
+    unsigned vo[5];
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+        const int u = wave * 5 + i;
+        const int t = u >> 2, g = u & 3;
+        vo[i] = (unsigned)((g * 8 + (lane >> 3)) * (3 * FD * 2) + t * 384 + (((lane & 7) ^ ((g * 4 + (lane >> 4)) & 7)) << 4));
+        asm volatile("" : "+v"(vo[i]));
+    }
+    auto dma_piece = [&](unsigned lds_dst, unsigned voff, uint64_t sbase) __attribute__((always_inline)) {
+        unsigned keep;
+        asm volatile(
+            "s_mov_b32 %0, m0\n\t"
+            "s_mov_b32 m0, %1\n\t"
+            "s_nop 0\n\t"
+            "global_load_lds_dwordx4 %2, %3\n\t"
+            "s_mov_b32 m0, %0"
+            : "=&s"(keep)
+            : "s"(lds_dst), "v"(voff), "s"(sbase)
+            : "memory");
+    };
+    auto w_base = [&](int c, int t) { return (uint64_t)(uintptr_t)p.W + (uint64_t)c * (LCH * 3 * FD * 2) + t * 128; };
+    auto w_dst = [&](int slot, int i) { return lds_base + slot * LW_STAGE + (wave * 5 + i) * 1024; };
+
+#pragma unroll
+    for (int i = 0; i < 5; ++i) dma_piece(w_dst(0, i), vo[i], w_base(0, 0));
+
+    bf16x8_t xf[FD / 16];
+    {
+        const bf16_t* xr = p.X + grow(fr) * p.ldx + fh * 8;
+#pragma unroll
+        for (int kk = 0; kk < FD / 16; ++kk) xf[kk] = *reinterpret_cast<const bf16x8_t*>(xr + kk * 16);
+        for (int i = tid; i < FD; i += 256) {            // one clip per workgroup: a = gamma rstd, b = beta - mean a
+            const float2 st = p.gn_stats[(size_t)b * p.gn_groups + i / (FD / p.gn_groups)];
+            const float a = p.gn_g[i] * st.y;
+            lns[i] = a; lns[FD + i] = p.gn_b[i] - st.x * a;
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    affine_rows_inplace<FD, true>(xf, lns, lns + FD, fh);
+
+    constexpr int PD = 6;
+    int slot = 0;
+    const int nch = p.N / LCH;
+    for (int c = 0; c < nch; ++c) {
+        f32x16_t y[3];
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+            if (c > 0 || t > 0) {
+                // this stage was issued during the previous one, in front of the loads / stores that closed a chunk
+                if (t == 0) { if (RES) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); }
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+            }
+            const char* s1 = smem + slot * LW_STAGE;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) y[t][r] = 0.f;
+            bf16x8_t wr[PD];
+            auto rd = [&](int kk, int sl) __attribute__((always_inline)) {
+                wr[sl] = *(lds_vfrag_t*)((lds_char_t*)s1 + (kk >> 2) * 4096 + off128(fr, (kk & 3) * 2 + fh));
+            };
+#pragma unroll
+            for (int kk = 0; kk < PD; ++kk) rd(kk, kk);
+            const bool more = t < 2 || c + 1 < nch;
+            const uint64_t nb = t < 2 ? w_base(c, t + 1) : w_base(c + 1, 0);
+#pragma unroll
+            for (int kk = 0; kk < FD / 16; ++kk) {
+                bf16x8_t f = wr[kk % PD];
+                if (kk + PD < FD / 16) rd(kk + PD, kk % PD);
+                asm volatile("" : "+v"(f));
+                y[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f, xf[kk], y[t], 0, 0, 0);
+                if (kk < 5 && more) dma_piece(w_dst(slot ^ 1, kk), vo[kk], nb);
+            }
+            slot ^= 1;
+        }
+        // ---- out[f] = Y0[f-1] + Y1[f] + Y2[f+1]: lanes of a 16-lane row are the 16 frames of one position
+        {
+            const int n0 = c * LCH;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 bv = *reinterpret_cast<const float4*>(p.bias + n0 + 8 * q + 4 * fh);
+                float o4[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    // (copies first: __builtin_bit_cast applied to a vector ELEMENT reads element 0 with this hipcc)
+                    const float y0 = y[0][4 * q + i], y2 = y[2][4 * q + i];
+                    const float prev = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(y0), 0x111, 0xf, 0xf, false));   // row_shr:1
+                    const float next = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(y2), 0x101, 0xf, 0xf, false));   // row_shl:1
+                    o4[i] = y[1][4 * q + i] + prev + next;
+                }
+                uint2 pk;
+                pk.x = pack_bf2(o4[0] + bv.x, o4[1] + bv.y);
+                pk.y = pack_bf2(o4[2] + bv.z, o4[3] + bv.w);
+                *reinterpret_cast<uint2*>(ebuf + fr * 64 + (((2 * q + fh) ^ (((fr >> 1) & 3) << 1)) << 3)) = pk;
+            }
+            const int rrow = lane >> 2, rc = lane & 3;
+            u32x4_t rres[2];
+            if constexpr (RES) {
+#pragma unroll
+                for (int t = 0; t < 2; ++t) rres[t] = *reinterpret_cast<const u32x4_t*>(p.R + grow(t * 16 + rrow) * p.ldr + n0 + rc * 8);
+            }
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int r = t * 16 + rrow;
+                u32x4_t d = *reinterpret_cast<const u32x4_t*>(ebuf + r * 64 + ((rc ^ ((r >> 1) & 3)) << 4));
+                if constexpr (RES) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        d[e] = pack_bf2(__uint_as_float(d[e] << 16) + __uint_as_float(rres[t][e] << 16),
+                                        __uint_as_float(d[e] & 0xffff0000u) + __uint_as_float(rres[t][e] & 0xffff0000u));
+                }
+                *reinterpret_cast<u32x4_t*>(p.O + grow(r) * p.ldo + n0 + rc * 8) = d;
+            }
+        }
+    }
+}
+
 }  // namespace
 
 #ifdef DC_FF_STAMPS
@@ -1111,6 +1275,33 @@ extern "C" int dc_ln_qkv_temporal_attn320(const uint16_t* x, int ldx, const floa
     p.X = x; p.ldx = ldx; p.W = wqkv; p.O = out; p.ldo = ldo; p.ln_g = ln_gamma; p.ln_b = ln_beta; p.ln_eps = ln_eps;
     p.HW = HW; p.c = scale * 1.4426950408889634f;
     hipLaunchKernelGGL(ln_qkv_tattn320_kernel, dim3((unsigned)(B * (HW / 8))), dim3(256), TA_LDS, (hipStream_t)stream_, p);
+    DC_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int dc_gn_silu_tconv3_320(const uint16_t* x, int ldx, const float* gamma, const float* beta, const float* stats,
+                                     int groups, const uint16_t* w, const float* bias, const uint16_t* residual, int ldr,
+                                     uint16_t* out, int ldo, int B, int T, int HW, int N, void* stream_) {
+    if (!x || !gamma || !beta || !stats || !w || !bias || !out) return DC_ERR_ARG;
+    if (B < 1 || T != 16 || HW < 8 || HW % 8 || N < LCH || N % LCH || ldx % 8 || ldo % 8 || (residual && ldr % 8)) return DC_ERR_SHAPE;
+    if (groups < 1 || FD % groups) return DC_ERR_SHAPE;
+    if (((uintptr_t)x | (uintptr_t)out | (uintptr_t)w | (uintptr_t)(residual ? residual : out)) % 16) return DC_ERR_SHAPE;
+    static bool configured = false;
+    if (!configured) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gn_silu_tconv320_kernel<false>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, ll_lds(1));
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gn_silu_tconv320_kernel<true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, ll_lds(1));
+        if (e != hipSuccess) return (int)e;
+        configured = true;
+    }
+    TcParams p;
+    p.X = x; p.ldx = ldx; p.W = w; p.bias = bias; p.R = residual; p.ldr = ldr; p.O = out; p.ldo = ldo;
+    p.gn_g = gamma; p.gn_b = beta; p.gn_stats = reinterpret_cast<const float2*>(stats); p.gn_groups = groups; p.HW = HW; p.N = N;
+    const dim3 grid((unsigned)(B * (HW / 8)));
+    if (residual) hipLaunchKernelGGL(gn_silu_tconv320_kernel<true>, grid, dim3(256), ll_lds(1), (hipStream_t)stream_, p);
+    else hipLaunchKernelGGL(gn_silu_tconv320_kernel<false>, grid, dim3(256), ll_lds(1), (hipStream_t)stream_, p);
     DC_CHECK_LAUNCH();
     return 0;
 }

@@ -29,6 +29,7 @@ _FF_FUSED = os.environ.get("DC_FF_FUSED", "1") != "0"
 _LN_FUSED = os.environ.get("DC_LN_FUSED", "1") != "0"      # A/B switches of the fused kernels in ff_fused.hip
 _TA_FUSED = os.environ.get("DC_TA_FUSED", "1") != "0"
 _FFP_FUSED = os.environ.get("DC_FFP_FUSED", "1") != "0"
+_TC_FUSED = os.environ.get("DC_TC_FUSED", "1") != "0"
 _FUSED_MIN_ROWS = int(os.environ.get("DC_FUSED_MIN_ROWS", "32768"))     # below this the tile GEMMs + norm kernels are used
 _LN_FUSED_K = tuple(int(k) for k in os.environ.get("DC_LN_FUSED_K", "320,640").split(","))
 C_IN_PAD = 64   # conv_in consumes the 8 latent+concat channels zero-padded to one 64-wide K slice
@@ -395,10 +396,19 @@ class UNetModel(nn.Module):
             return h2
         tc = dict(T=g["T"], HW=g["HW"])
         r = h2
+        fused_tc = (_TC_FUSED and cout == 320 and g["T"] == 16 and g["HW"] % 8 == 0 and M >= _FUSED_MIN_ROWS
+                    and (g["T"] * g["HW"]) % 128 == 0)
         for i, (gnw, cw) in enumerate(W["tc"]):
-            n = self._gn(r, gnw, "gn", n_inst=g["B"], rpi=g["T"] * g["HW"], eps=1e-5, silu=True)
             last = i == 3
             dst = final() if last else A.get("res_ta" if i % 2 == 0 else "res_tb", M, cout, device=dev)
+            if fused_tc:
+                # level 0: GroupNorm statistics pass, then normalise + SiLU + the three taps + bias (+ identity) in one kernel
+                st = A.get("gn_stats", g["B"] * 32 * 2, 1, torch.float32, dev)
+                ops.groupnorm_stats(r, st, groups=32, n_inst=g["B"], rows_per_inst=g["T"] * g["HW"], eps=1e-5)
+                r = ops.gn_silu_tconv3_320(r, gnw[0], gnw[1], st, cw, dst, B=g["B"], T=16, HW=g["HW"],
+                                           residual=h2 if last else None)
+                continue
+            n = self._gn(r, gnw, "gn", n_inst=g["B"], rpi=g["T"] * g["HW"], eps=1e-5, silu=True)
             r = ops.gemm(n, cw, dst, tconv=tc, residual=h2 if last else None)
         return r
 

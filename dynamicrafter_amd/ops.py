@@ -476,6 +476,26 @@ def ln_qkv_temporal_attn320(x, ln, pw_qkv, out, *, B, T, HW, scale, ln_eps=1e-5)
     return out
 
 
+def gn_silu_tconv3_320(x, gamma, beta, stats, pw, out, *, B, T, HW, groups=32, residual=None):
+    """out = tconv3(silu(GroupNorm(x))) (+ residual) for 320 input channels, statistics from groupnorm_stats over the clips
+    (n_inst = B, rows_per_inst = T * HW); pw = PackedWeight.tconv3; rows ordered (clip, frame, position)."""
+    _rows(x, "x"); _rows(out, "out")
+    M = B * T * HW
+    if pw.w.shape[1] != 960 or pw.N % 32 or pw.bias is None or T != 16 or HW % 8:
+        raise ValueError("gn_silu_tconv3_320: 320 input channels (weight [N, 960] with bias), N % 32 == 0, T = 16, HW % 8 == 0")
+    if x.data_ptr() == out.data_ptr():
+        raise ValueError("gn_silu_tconv3_320: out must not alias x")
+    _need_rows(x, M, 320, "x"); _need_rows(out, M, pw.N, "out")
+    _need(gamma, 320, "gamma"); _need(beta, 320, "beta"); _need(stats, B * groups * 2, "stats")
+    if residual is not None:
+        _rows(residual, "residual"); _need_rows(residual, M, pw.N, "residual")
+    _launch("gn_silu_tconv3_320", 2.0 * M * pw.N * 960, 2.0 * M * (320 + pw.N * (2 if residual is not None else 1)) + 2.0 * pw.N * 960,
+            _hip.lib().dc_gn_silu_tconv3_320, _ptr(x), x.stride(0), _ptr(gamma), _ptr(beta), _ptr(stats), groups, _ptr(pw.w),
+            _ptr(pw.bias), _ptr(residual), 0 if residual is None else residual.stride(0), _ptr(out), out.stride(0), B, T, HW,
+            pw.N, stream_ptr())
+    return out
+
+
 def groupnorm_stats(x, stats, *, groups, n_inst, rows_per_inst, eps):
     """(mean, rstd) per (instance, group) of channels-last rows -> stats fp32 [n_inst, groups, 2] (for gn_linear320)."""
     _rows(x, "x")

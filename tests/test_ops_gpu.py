@@ -732,6 +732,38 @@ def test_ln_qkv_temporal_attn320_vs_three_kernels(ops, B, HW):
         ops.ln_qkv_temporal_attn320(xd, (gd, bd), pw, xd, B=B, T=T, HW=HW, scale=0.125)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,HW", [(1, 8), (2, 72), (2, 2304)])
+def test_gn_silu_tconv3_320_vs_groupnorm_plus_tconv(ops, B, HW):
+    """dc_groupnorm_stats + dc_gn_silu_tconv3_320 = dc_groupnorm(silu) + dc_gemm_conv(tconv) (+ residual), and = torch fp32
+    GroupNorm -> SiLU -> Conv3d (3,1,1)"""
+    g = torch.Generator().manual_seed(7 * B + HW)
+    T, C = 16, 320
+    M = B * T * HW
+    x = (torch.randn(M, C, generator=g) * (1 + torch.arange(C) % 5 * 0.4) + 0.3).to(torch.bfloat16)
+    w = torch.randn(C, C, 3, 1, 1, generator=g) * (3 * C) ** -0.5
+    bias = torch.randn(C, generator=g) * 0.1
+    res = torch.randn(M, C, generator=g).to(torch.bfloat16)
+    gam = (1 + 0.2 * torch.randn(C, generator=g)).to(DEV); bet = (0.3 * torch.randn(C, generator=g)).to(DEV)
+    pw = ops.PackedWeight.tconv3(w, bias, DEV)
+    xd, rd = x.to(DEV), res.to(DEV)
+    st = torch.empty(B * 32 * 2, dtype=torch.float32, device=DEV)
+    ops.groupnorm_stats(xd, st, groups=32, n_inst=B, rows_per_inst=T * HW, eps=1e-5)
+    n = torch.empty_like(xd)
+    ops.groupnorm(xd, n, gam, bet, groups=32, n_inst=B, rows_per_inst=T * HW, eps=1e-5, silu=True)
+    for residual in (None, rd):
+        out = torch.empty(M, C, dtype=torch.bfloat16, device=DEV)
+        ops.gn_silu_tconv3_320(xd, gam, bet, st, pw, out, B=B, T=T, HW=HW, residual=residual)
+        want = torch.empty_like(out)
+        ops.gemm(n, pw, want, tconv=dict(T=T, HW=HW), residual=residual)
+        assert rel_l2(out, want) < 3e-3
+    x5 = x.float().reshape(B, T, HW, C).permute(0, 3, 1, 2)                            # [B, C, T, HW]
+    a = torch.nn.functional.silu(torch.nn.functional.group_norm(x5, 32, gam.cpu(), bet.cpu(), 1e-5))
+    ref = torch.nn.functional.conv3d(a.unsqueeze(-1), w, bias, padding=(1, 0, 0)).squeeze(-1)      # [B, C, T, HW]
+    ref = ref.permute(0, 2, 3, 1).reshape(M, C) + res.float()
+    assert rel_l2(out.float().cpu(), ref) < 8e-3
+
+
 @pytest.mark.parametrize("M", [128 * 5, 1000, 40000])
 def test_ff_geglu_fused320_vs_torch(ops, M):
     """ff1 -> GEGLU -> ff2 (+ residual) in one kernel (dim 320) vs fp32 torch and vs the two-GEMM path."""

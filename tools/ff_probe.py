@@ -62,3 +62,22 @@ for name, fn in (("ln_qkv+tattn", three), ("fused", fusedta), ("ln_qkv+tattn", t
     for _ in range(10): fn()
     e1.record(); torch.cuda.synchronize()
     print(f"{name:13s} M={M}: {e0.elapsed_time(e1) / 10 * 1e3:8.1f} us", flush=True)
+
+# GroupNorm + SiLU + temporal conv in one kernel vs GroupNorm kernels + implicit-GEMM tconv (level 0)
+wt = torch.randn(320, 320, 3, 1, 1, generator=g) * 960 ** -0.5
+pwt = ops.PackedWeight.tconv3(wt, torch.zeros(320), DEV)
+st = torch.empty(Bc * 64, dtype=torch.float32, device=DEV); nn2 = torch.empty_like(h); o2 = torch.empty_like(h)
+def gn_tc():
+    ops.groupnorm(h, nn2, gam, bet, groups=32, n_inst=Bc, rows_per_inst=T * HW, eps=1e-5, silu=True)
+    ops.gemm(nn2, pwt, o2, tconv=dict(T=T, HW=HW))
+def fused_tc():
+    ops.groupnorm_stats(h, st, groups=32, n_inst=Bc, rows_per_inst=T * HW, eps=1e-5)
+    ops.gn_silu_tconv3_320(h, gam, bet, st, pwt, o2, B=Bc, T=T, HW=HW)
+for name, fn in (("gn+tconv", gn_tc), ("fused", fused_tc), ("gn+tconv", gn_tc), ("fused", fused_tc)):
+    for _ in range(2): fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(10): fn()
+    e1.record(); torch.cuda.synchronize()
+    print(f"{name:13s} M={M}: {e0.elapsed_time(e1) / 10 * 1e3:8.1f} us", flush=True)
