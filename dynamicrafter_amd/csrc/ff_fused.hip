@@ -993,17 +993,20 @@ void ln_qkv_tattn320_kernel(const TaParams p) {
 // is two DPP row shifts (16-lane rows = the 16 frames of a position; the shifted-in lane is 0 = the zero padding).
 struct TcParams {
     const bf16_t* X; int ldx;
-    const bf16_t* W;             // PackedWeight.tconv3: [>= N][960], k = (64-channel slice, tap, channel in slice)
+    const bf16_t* W;             // PackedWeight.tconv3: [>= N][3 C], k = (64-channel slice, tap, channel in slice)
     const float* bias;           // [N]
     const bf16_t* R; int ldr;    // residual rows or nullptr
     bf16_t* O; int ldo;
     const float* gn_g; const float* gn_b; const float2* gn_stats; int gn_groups;      // stats [clip][group] = (mean, rstd)
     int HW, N;
+    int nsplit, cpp;             // workgroups per row tile, chunks per workgroup (few row tiles: split N)
 };
 
-template <bool RES>
+// C = 320 KH input channels; the taps run in the order 1, 0, 2 so that only `out` and the current product are live
+template <int KH, bool RES>
 __global__ __launch_bounds__(256, 2)
-void gn_silu_tconv320_kernel(const TcParams p) {
+void gn_silu_tconv_kernel(const TcParams p) {
+    constexpr int KD = FD * KH;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -1012,18 +1015,23 @@ void gn_silu_tconv320_kernel(const TcParams p) {
     const unsigned lds_base = (unsigned)(unsigned long)((lds_char_t*)smem);
     char* const ebuf = smem + 2 * LW_STAGE + wave * 2048;
     float* const lns = reinterpret_cast<float*>(smem + 2 * LW_STAGE + 4 * 2048);
+    const int tile = (int)blockIdx.x / p.nsplit, part = (int)blockIdx.x - tile * p.nsplit;
     const int gpb = p.HW >> 3;
-    const int b = (int)blockIdx.x / gpb, p0 = ((int)blockIdx.x - b * gpb) * 8 + 2 * wave;
+    const int b = tile / gpb, p0 = (tile - b * gpb) * 8 + 2 * wave;
     auto grow = [&](int r) { return ((size_t)(b * 16 + (r & 15))) * p.HW + p0 + (r >> 4); };      // wave row r -> tensor row
+    const int c_begin = part * p.cpp;
+    int c_end = c_begin + p.cpp;
+    if (c_end > p.N / LCH) c_end = p.N / LCH;
+    if (c_begin >= c_end) return;
 
-    // LDS-DMA of stage (chunk c, tap t): 32 weight rows x the tap's 320 channels = 5 K tiles of [32 rows][128 B]; in the
-    // packed weight a K tile (64-channel slice s) of tap t starts at column 192 s + 64 t
+    // LDS-DMA of stage (chunk c, tap t, k half h): 32 weight rows x 320 channels of the tap = 5 K tiles of [32 rows][128 B];
+    // in the packed weight the K tile of 64-channel slice s and tap t starts at column 192 s + 64 t
     unsigned vo[5];
 #pragma unroll
     for (int i = 0; i < 5; ++i) {
         const int u = wave * 5 + i;
         const int t = u >> 2, g = u & 3;
-        vo[i] = (unsigned)((g * 8 + (lane >> 3)) * (3 * FD * 2) + t * 384 + (((lane & 7) ^ ((g * 4 + (lane >> 4)) & 7)) << 4));
+        vo[i] = (unsigned)((g * 8 + (lane >> 3)) * (3 * KD * 2) + t * 384 + (((lane & 7) ^ ((g * 4 + (lane >> 4)) & 7)) << 4));
         asm volatile("" : "+v"(vo[i]));
     }
     auto dma_piece = [&](unsigned lds_dst, unsigned voff, uint64_t sbase) __attribute__((always_inline)) {
@@ -1038,81 +1046,92 @@ void gn_silu_tconv320_kernel(const TcParams p) {
             : "s"(lds_dst), "v"(voff), "s"(sbase)
             : "memory");
     };
-    auto w_base = [&](int c, int t) { return (uint64_t)(uintptr_t)p.W + (uint64_t)c * (LCH * 3 * FD * 2) + t * 128; };
+    // stage index within a chunk: j = 0 .. 3 KH - 1, tap = order[j / KH], half = j % KH
+    auto w_base = [&](int c, int j) {
+        const int jt = j / KH, h = j - jt * KH;
+        const int tap = jt == 0 ? 1 : (jt == 1 ? 0 : 2);
+        return (uint64_t)(uintptr_t)p.W + (uint64_t)c * (LCH * 3 * KD * 2) + tap * 128 + h * (5 * 384);
+    };
     auto w_dst = [&](int slot, int i) { return lds_base + slot * LW_STAGE + (wave * 5 + i) * 1024; };
 
 #pragma unroll
-    for (int i = 0; i < 5; ++i) dma_piece(w_dst(0, i), vo[i], w_base(0, 0));
+    for (int i = 0; i < 5; ++i) dma_piece(w_dst(0, i), vo[i], w_base(c_begin, 0));
 
-    bf16x8_t xf[FD / 16];
+    bf16x8_t xf[KD / 16];
     {
         const bf16_t* xr = p.X + grow(fr) * p.ldx + fh * 8;
 #pragma unroll
-        for (int kk = 0; kk < FD / 16; ++kk) xf[kk] = *reinterpret_cast<const bf16x8_t*>(xr + kk * 16);
-        for (int i = tid; i < FD; i += 256) {            // one clip per workgroup: a = gamma rstd, b = beta - mean a
-            const float2 st = p.gn_stats[(size_t)b * p.gn_groups + i / (FD / p.gn_groups)];
+        for (int kk = 0; kk < KD / 16; ++kk) xf[kk] = *reinterpret_cast<const bf16x8_t*>(xr + kk * 16);
+        for (int i = tid; i < KD; i += 256) {            // one clip per workgroup: a = gamma rstd, b = beta - mean a
+            const float2 st = p.gn_stats[(size_t)b * p.gn_groups + i / (KD / p.gn_groups)];
             const float a = p.gn_g[i] * st.y;
-            lns[i] = a; lns[FD + i] = p.gn_b[i] - st.x * a;
+            lns[i] = a; lns[KD + i] = p.gn_b[i] - st.x * a;
         }
     }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    affine_rows_inplace<FD, true>(xf, lns, lns + FD, fh);
+    affine_rows_inplace<KD, true>(xf, lns, lns + KD, fh);
 
-    constexpr int PD = 6;
+    constexpr int PD = KH == 1 ? 6 : 3;                  // K = 640: 160 registers of X fragments, a shorter LDS read window fits 256
+    constexpr int NS = 3 * KH;                           // stages per chunk
     int slot = 0;
-    const int nch = p.N / LCH;
-    for (int c = 0; c < nch; ++c) {
-        f32x16_t y[3];
+    for (int c = c_begin; c < c_end; ++c) {
+        f32x16_t out, y;
 #pragma unroll
-        for (int t = 0; t < 3; ++t) {
-            if (c > 0 || t > 0) {
+        for (int j = 0; j < NS; ++j) {
+            const int jt = j / KH, h = j % KH;            // jt 0: tap 1 (centre) -> out; 1: tap 0 (frame - 1); 2: tap 2 (frame + 1)
+            if (c > c_begin || j > 0) {
                 // this stage was issued during the previous one, in front of the loads / stores that closed a chunk
-                if (t == 0) { if (RES) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); }
+                if (j == 0) { if (RES) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); }
                 else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
                 asm volatile("" ::: "memory");
             }
             const char* s1 = smem + slot * LW_STAGE;
+            f32x16_t& acc = jt == 0 ? out : y;
+            if (h == 0) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) y[t][r] = 0.f;
+                for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+            }
             bf16x8_t wr[PD];
             auto rd = [&](int kk, int sl) __attribute__((always_inline)) {
                 wr[sl] = *(lds_vfrag_t*)((lds_char_t*)s1 + (kk >> 2) * 4096 + off128(fr, (kk & 3) * 2 + fh));
             };
 #pragma unroll
             for (int kk = 0; kk < PD; ++kk) rd(kk, kk);
-            const bool more = t < 2 || c + 1 < nch;
-            const uint64_t nb = t < 2 ? w_base(c, t + 1) : w_base(c + 1, 0);
+            const bool more = j + 1 < NS || c + 1 < c_end;
+            const uint64_t nb = j + 1 < NS ? w_base(c, j + 1) : w_base(c + 1, 0);
 #pragma unroll
             for (int kk = 0; kk < FD / 16; ++kk) {
                 bf16x8_t f = wr[kk % PD];
                 if (kk + PD < FD / 16) rd(kk + PD, kk % PD);
                 asm volatile("" : "+v"(f));
-                y[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f, xf[kk], y[t], 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f, xf[h * (FD / 16) + kk], acc, 0, 0, 0);
                 if (kk < 5 && more) dma_piece(w_dst(slot ^ 1, kk), vo[kk], nb);
             }
             slot ^= 1;
+            if (jt > 0 && h == KH - 1) {
+                // out[f] += Y_0[f - 1] (row_shr:1) resp. Y_2[f + 1] (row_shl:1): the 16 lanes of a DPP row are the 16 frames
+                // of one position, the lane shifted in from outside the row is 0 = the zero padding in time
+                // (copies first: __builtin_bit_cast applied to a vector ELEMENT reads element 0 with this hipcc)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float yv = y[r];
+                    out[r] += __int_as_float(jt == 1 ? __builtin_amdgcn_update_dpp(0, __float_as_int(yv), 0x111, 0xf, 0xf, false)
+                                                     : __builtin_amdgcn_update_dpp(0, __float_as_int(yv), 0x101, 0xf, 0xf, false));
+                }
+            }
         }
-        // ---- out[f] = Y0[f-1] + Y1[f] + Y2[f+1]: lanes of a 16-lane row are the 16 frames of one position
+        // ---- chunk epilogue: + bias, bf16, (+ residual), row-major through the wave-private patch; rows scattered back
         {
             const int n0 = c * LCH;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const float4 bv = *reinterpret_cast<const float4*>(p.bias + n0 + 8 * q + 4 * fh);
-                float o4[4];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    // (copies first: __builtin_bit_cast applied to a vector ELEMENT reads element 0 with this hipcc)
-                    const float y0 = y[0][4 * q + i], y2 = y[2][4 * q + i];
-                    const float prev = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(y0), 0x111, 0xf, 0xf, false));   // row_shr:1
-                    const float next = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(y2), 0x101, 0xf, 0xf, false));   // row_shl:1
-                    o4[i] = y[1][4 * q + i] + prev + next;
-                }
                 uint2 pk;
-                pk.x = pack_bf2(o4[0] + bv.x, o4[1] + bv.y);
-                pk.y = pack_bf2(o4[2] + bv.z, o4[3] + bv.w);
+                pk.x = pack_bf2(out[4 * q] + bv.x, out[4 * q + 1] + bv.y);
+                pk.y = pack_bf2(out[4 * q + 2] + bv.z, out[4 * q + 3] + bv.w);
                 *reinterpret_cast<uint2*>(ebuf + fr * 64 + (((2 * q + fh) ^ (((fr >> 1) & 3) << 1)) << 3)) = pk;
             }
             const int rrow = lane >> 2, rc = lane & 3;
@@ -1279,29 +1298,38 @@ extern "C" int dc_ln_qkv_temporal_attn320(const uint16_t* x, int ldx, const floa
     return 0;
 }
 
-extern "C" int dc_gn_silu_tconv3_320(const uint16_t* x, int ldx, const float* gamma, const float* beta, const float* stats,
-                                     int groups, const uint16_t* w, const float* bias, const uint16_t* residual, int ldr,
-                                     uint16_t* out, int ldo, int B, int T, int HW, int N, void* stream_) {
-    if (!x || !gamma || !beta || !stats || !w || !bias || !out) return DC_ERR_ARG;
-    if (B < 1 || T != 16 || HW < 8 || HW % 8 || N < LCH || N % LCH || ldx % 8 || ldo % 8 || (residual && ldr % 8)) return DC_ERR_SHAPE;
-    if (groups < 1 || FD % groups) return DC_ERR_SHAPE;
-    if (((uintptr_t)x | (uintptr_t)out | (uintptr_t)w | (uintptr_t)(residual ? residual : out)) % 16) return DC_ERR_SHAPE;
+template <int KH, bool RES>
+static int launch_gn_silu_tconv(const TcParams& p, dim3 grid, hipStream_t stream) {
     static bool configured = false;
     if (!configured) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gn_silu_tconv320_kernel<false>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, ll_lds(1));
-        if (e == hipSuccess)
-            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gn_silu_tconv320_kernel<true>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, ll_lds(1));
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gn_silu_tconv_kernel<KH, RES>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, ll_lds(KH));
         if (e != hipSuccess) return (int)e;
         configured = true;
     }
+    hipLaunchKernelGGL((gn_silu_tconv_kernel<KH, RES>), grid, dim3(256), ll_lds(KH), stream, p);
+    DC_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int dc_gn_silu_tconv3(const uint16_t* x, int ldx, int C, const float* gamma, const float* beta, const float* stats,
+                                 int groups, const uint16_t* w, const float* bias, const uint16_t* residual, int ldr,
+                                 uint16_t* out, int ldo, int B, int T, int HW, int N, void* stream_) {
+    if (!x || !gamma || !beta || !stats || !w || !bias || !out) return DC_ERR_ARG;
+    if ((C != FD && C != 2 * FD) || B < 1 || T != 16 || HW < 8 || HW % 8 || N < LCH || N % LCH || ldx % 8 || ldo % 8 ||
+        (residual && ldr % 8)) return DC_ERR_SHAPE;
+    if (groups < 1 || C % groups) return DC_ERR_SHAPE;
+    if (((uintptr_t)x | (uintptr_t)out | (uintptr_t)w | (uintptr_t)(residual ? residual : out)) % 16) return DC_ERR_SHAPE;
     TcParams p;
     p.X = x; p.ldx = ldx; p.W = w; p.bias = bias; p.R = residual; p.ldr = ldr; p.O = out; p.ldo = ldo;
     p.gn_g = gamma; p.gn_b = beta; p.gn_stats = reinterpret_cast<const float2*>(stats); p.gn_groups = groups; p.HW = HW; p.N = N;
-    const dim3 grid((unsigned)(B * (HW / 8)));
-    if (residual) hipLaunchKernelGGL(gn_silu_tconv320_kernel<true>, grid, dim3(256), ll_lds(1), (hipStream_t)stream_, p);
-    else hipLaunchKernelGGL(gn_silu_tconv320_kernel<false>, grid, dim3(256), ll_lds(1), (hipStream_t)stream_, p);
-    DC_CHECK_LAUNCH();
-    return 0;
+    // few row tiles: split N over several workgroups per tile until the launch has >= 3 rounds of work for its slots
+    const int tiles = B * (HW / 8), nch = N / LCH, slots = 256 * 2;
+    int nsplit = 1;
+    while (tiles * nsplit < 3 * slots && nsplit * 2 <= nch && nch / (nsplit * 2) >= 5) nsplit *= 2;
+    p.nsplit = nsplit; p.cpp = (nch + nsplit - 1) / nsplit;
+    const dim3 grid((unsigned)(tiles * nsplit));
+    hipStream_t stream = (hipStream_t)stream_;
+    if (C == FD) return residual ? launch_gn_silu_tconv<1, true>(p, grid, stream) : launch_gn_silu_tconv<1, false>(p, grid, stream);
+    return residual ? launch_gn_silu_tconv<2, true>(p, grid, stream) : launch_gn_silu_tconv<2, false>(p, grid, stream);
 }

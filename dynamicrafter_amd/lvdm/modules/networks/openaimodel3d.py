@@ -396,16 +396,16 @@ class UNetModel(nn.Module):
             return h2
         tc = dict(T=g["T"], HW=g["HW"])
         r = h2
-        fused_tc = (_TC_FUSED and cout == 320 and g["T"] == 16 and g["HW"] % 8 == 0 and M >= _FUSED_MIN_ROWS
+        fused_tc = (_TC_FUSED and cout in _LN_FUSED_K and g["T"] == 16 and g["HW"] % 8 == 0 and M >= _FUSED_MIN_ROWS
                     and (g["T"] * g["HW"]) % 128 == 0)
         for i, (gnw, cw) in enumerate(W["tc"]):
             last = i == 3
             dst = final() if last else A.get("res_ta" if i % 2 == 0 else "res_tb", M, cout, device=dev)
             if fused_tc:
-                # level 0: GroupNorm statistics pass, then normalise + SiLU + the three taps + bias (+ identity) in one kernel
+                # levels 0 / 1: GroupNorm statistics pass, then normalise + SiLU + the three taps + bias (+ identity) in one kernel
                 st = A.get("gn_stats", g["B"] * 32 * 2, 1, torch.float32, dev)
                 ops.groupnorm_stats(r, st, groups=32, n_inst=g["B"], rows_per_inst=g["T"] * g["HW"], eps=1e-5)
-                r = ops.gn_silu_tconv3_320(r, gnw[0], gnw[1], st, cw, dst, B=g["B"], T=16, HW=g["HW"],
+                r = ops.gn_silu_tconv3(r, gnw[0], gnw[1], st, cw, dst, B=g["B"], T=16, HW=g["HW"],
                                            residual=h2 if last else None)
                 continue
             n = self._gn(r, gnw, "gn", n_inst=g["B"], rpi=g["T"] * g["HW"], eps=1e-5, silu=True)

@@ -476,21 +476,22 @@ def ln_qkv_temporal_attn320(x, ln, pw_qkv, out, *, B, T, HW, scale, ln_eps=1e-5)
     return out
 
 
-def gn_silu_tconv3_320(x, gamma, beta, stats, pw, out, *, B, T, HW, groups=32, residual=None):
-    """out = tconv3(silu(GroupNorm(x))) (+ residual) for 320 input channels, statistics from groupnorm_stats over the clips
-    (n_inst = B, rows_per_inst = T * HW); pw = PackedWeight.tconv3; rows ordered (clip, frame, position)."""
+def gn_silu_tconv3(x, gamma, beta, stats, pw, out, *, B, T, HW, groups=32, residual=None):
+    """out = tconv3(silu(GroupNorm(x))) (+ residual) for 320 / 640 input channels, statistics from groupnorm_stats over the
+    clips (n_inst = B, rows_per_inst = T * HW); pw = PackedWeight.tconv3; rows ordered (clip, frame, position)."""
     _rows(x, "x"); _rows(out, "out")
     M = B * T * HW
-    if pw.w.shape[1] != 960 or pw.N % 32 or pw.bias is None or T != 16 or HW % 8:
-        raise ValueError("gn_silu_tconv3_320: 320 input channels (weight [N, 960] with bias), N % 32 == 0, T = 16, HW % 8 == 0")
+    C = pw.w.shape[1] // 3
+    if C not in (320, 640) or pw.w.shape[1] != 3 * C or pw.N % 32 or pw.bias is None or T != 16 or HW % 8:
+        raise ValueError("gn_silu_tconv3: 320 / 640 input channels (weight [N, 3 C] with bias), N % 32 == 0, T = 16, HW % 8 == 0")
     if x.data_ptr() == out.data_ptr():
-        raise ValueError("gn_silu_tconv3_320: out must not alias x")
-    _need_rows(x, M, 320, "x"); _need_rows(out, M, pw.N, "out")
-    _need(gamma, 320, "gamma"); _need(beta, 320, "beta"); _need(stats, B * groups * 2, "stats")
+        raise ValueError("gn_silu_tconv3: out must not alias x")
+    _need_rows(x, M, C, "x"); _need_rows(out, M, pw.N, "out")
+    _need(gamma, C, "gamma"); _need(beta, C, "beta"); _need(stats, B * groups * 2, "stats")
     if residual is not None:
         _rows(residual, "residual"); _need_rows(residual, M, pw.N, "residual")
-    _launch("gn_silu_tconv3_320", 2.0 * M * pw.N * 960, 2.0 * M * (320 + pw.N * (2 if residual is not None else 1)) + 2.0 * pw.N * 960,
-            _hip.lib().dc_gn_silu_tconv3_320, _ptr(x), x.stride(0), _ptr(gamma), _ptr(beta), _ptr(stats), groups, _ptr(pw.w),
+    _launch("gn_silu_tconv3", 2.0 * M * pw.N * 3 * C, 2.0 * M * (C + pw.N * (2 if residual is not None else 1)) + 2.0 * pw.N * 3 * C,
+            _hip.lib().dc_gn_silu_tconv3, _ptr(x), x.stride(0), C, _ptr(gamma), _ptr(beta), _ptr(stats), groups, _ptr(pw.w),
             _ptr(pw.bias), _ptr(residual), 0 if residual is None else residual.stride(0), _ptr(out), out.stride(0), B, T, HW,
             pw.N, stream_ptr())
     return out

@@ -233,13 +233,13 @@ int dc_ln_qkv_temporal_attn320(const uint16_t* x, int ldx, const float* ln_gamma
                                const uint16_t* wqkv, uint16_t* out, int ldo, int B, int T, int HW, float scale, void* stream);
 
 /* GroupNorm (statistics from dc_groupnorm_stats, instances = clips) + SiLU + temporal convolution (3,1,1), zero padding in
- * time, (+ residual) for 320 input channels in one launch; rows ordered (clip, frame, position), T = 16, HW % 8 == 0,
- * N % 32 == 0. w: the temporal-conv weight as dc_gemm_conv takes it (bf16 [>= N][960], k = (64-channel slice, tap, channel));
- * bias fp32 [N]. The activated copy never reaches HBM; roundings as dc_groupnorm (silu) -> dc_gemm_conv (tconv).
- * replaces TemporalConvBlock conv1..conv4 lvdm/modules/networks/openaimodel3d.py:239-279 at the UNet's level 0 */
-int dc_gn_silu_tconv3_320(const uint16_t* x, int ldx, const float* gamma, const float* beta, const float* stats, int groups,
-                          const uint16_t* w, const float* bias, const uint16_t* residual, int ldr, uint16_t* out, int ldo, int B,
-                          int T, int HW, int N, void* stream);
+ * time, (+ residual) for C = 320 or 640 input channels in one launch; rows ordered (clip, frame, position), T = 16,
+ * HW % 8 == 0, N % 32 == 0. w: the temporal-conv weight as dc_gemm_conv takes it (bf16 [>= N][3 C], k = (64-channel slice,
+ * tap, channel)); bias fp32 [N]. The activated copy never reaches HBM; roundings as dc_groupnorm (silu) -> dc_gemm_conv.
+ * replaces TemporalConvBlock conv1..conv4 lvdm/modules/networks/openaimodel3d.py:239-279 at the UNet's levels 0 and 1 */
+int dc_gn_silu_tconv3(const uint16_t* x, int ldx, int C, const float* gamma, const float* beta, const float* stats, int groups,
+                      const uint16_t* w, const float* bias, const uint16_t* residual, int ldr, uint16_t* out, int ldo, int B, int T,
+                      int HW, int N, void* stream);
 
 /* ---- conditioning encoders (once per clip) ---------------------------------------------------- */
 

@@ -733,12 +733,12 @@ def test_ln_qkv_temporal_attn320_vs_three_kernels(ops, B, HW):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("B,HW", [(1, 8), (2, 72), (2, 2304)])
-def test_gn_silu_tconv3_320_vs_groupnorm_plus_tconv(ops, B, HW):
-    """dc_groupnorm_stats + dc_gn_silu_tconv3_320 = dc_groupnorm(silu) + dc_gemm_conv(tconv) (+ residual), and = torch fp32
+@pytest.mark.parametrize("B,HW,C", [(1, 8, 320), (2, 72, 320), (2, 2304, 320), (2, 2304, 640), (1, 40, 640)])
+def test_gn_silu_tconv3_vs_groupnorm_plus_tconv(ops, B, HW, C):
+    """dc_groupnorm_stats + dc_gn_silu_tconv3 = dc_groupnorm(silu) + dc_gemm_conv(tconv) (+ residual), and = torch fp32
     GroupNorm -> SiLU -> Conv3d (3,1,1)"""
     g = torch.Generator().manual_seed(7 * B + HW)
-    T, C = 16, 320
+    T = 16
     M = B * T * HW
     x = (torch.randn(M, C, generator=g) * (1 + torch.arange(C) % 5 * 0.4) + 0.3).to(torch.bfloat16)
     w = torch.randn(C, C, 3, 1, 1, generator=g) * (3 * C) ** -0.5
@@ -753,7 +753,7 @@ def test_gn_silu_tconv3_320_vs_groupnorm_plus_tconv(ops, B, HW):
     ops.groupnorm(xd, n, gam, bet, groups=32, n_inst=B, rows_per_inst=T * HW, eps=1e-5, silu=True)
     for residual in (None, rd):
         out = torch.empty(M, C, dtype=torch.bfloat16, device=DEV)
-        ops.gn_silu_tconv3_320(xd, gam, bet, st, pw, out, B=B, T=T, HW=HW, residual=residual)
+        ops.gn_silu_tconv3(xd, gam, bet, st, pw, out, B=B, T=T, HW=HW, residual=residual)
         want = torch.empty_like(out)
         ops.gemm(n, pw, want, tconv=dict(T=T, HW=HW), residual=residual)
         assert rel_l2(out, want) < 3e-3

@@ -72,7 +72,7 @@ def gn_tc():
     ops.gemm(nn2, pwt, o2, tconv=dict(T=T, HW=HW))
 def fused_tc():
     ops.groupnorm_stats(h, st, groups=32, n_inst=Bc, rows_per_inst=T * HW, eps=1e-5)
-    ops.gn_silu_tconv3_320(h, gam, bet, st, pwt, o2, B=Bc, T=T, HW=HW)
+    ops.gn_silu_tconv3(h, gam, bet, st, pwt, o2, B=Bc, T=T, HW=HW)
 for name, fn in (("gn+tconv", gn_tc), ("fused", fused_tc), ("gn+tconv", gn_tc), ("fused", fused_tc)):
     for _ in range(2): fn()
     torch.cuda.synchronize()
@@ -81,3 +81,24 @@ for name, fn in (("gn+tconv", gn_tc), ("fused", fused_tc), ("gn+tconv", gn_tc), 
     for _ in range(10): fn()
     e1.record(); torch.cuda.synchronize()
     print(f"{name:13s} M={M}: {e0.elapsed_time(e1) / 10 * 1e3:8.1f} us", flush=True)
+
+# the same at level 1 (640 channels, a quarter of the rows)
+M1, HW1 = M // 4, HW // 4
+h1 = torch.randn(M1, 640, device=DEV).to(torch.bfloat16); g1 = torch.ones(640, device=DEV); b1_ = torch.zeros(640, device=DEV)
+wt1 = torch.randn(640, 640, 3, 1, 1, generator=g) * 1920 ** -0.5
+pwt1 = ops.PackedWeight.tconv3(wt1, torch.zeros(640), DEV)
+nn3 = torch.empty_like(h1); o3 = torch.empty_like(h1)
+def gn_tc1():
+    ops.groupnorm(h1, nn3, g1, b1_, groups=32, n_inst=Bc, rows_per_inst=T * HW1, eps=1e-5, silu=True)
+    ops.gemm(nn3, pwt1, o3, tconv=dict(T=T, HW=HW1))
+def fused_tc1():
+    ops.groupnorm_stats(h1, st, groups=32, n_inst=Bc, rows_per_inst=T * HW1, eps=1e-5)
+    ops.gn_silu_tconv3(h1, g1, b1_, st, pwt1, o3, B=Bc, T=T, HW=HW1)
+for name, fn in (("gn+tconv 640", gn_tc1), ("fused 640", fused_tc1), ("gn+tconv 640", gn_tc1), ("fused 640", fused_tc1)):
+    for _ in range(2): fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(10): fn()
+    e1.record(); torch.cuda.synchronize()
+    print(f"{name:13s} M={M1}: {e0.elapsed_time(e1) / 10 * 1e3:8.1f} us", flush=True)
