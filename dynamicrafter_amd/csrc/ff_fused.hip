@@ -1,4 +1,14 @@
-// Fused GEGLU FeedForward for dim = 320 (the UNet's level-0 transformers):
+// Kernels that keep the activation rows of a workgroup in REGISTERS as MFMA operand fragments ("X-stationary") and stream
+// only weights through LDS - the UNet's level-0 / level-1 row-wise operator chains, fused:
+//   ff_geglu_fused320_kernel   x = x + ff2(geglu(ff1(norm3(x))))  [+ the transformer's proj_out and residual]      dim 320
+//   norm_linear_kernel         Linear(LayerNorm(x)) / Linear(GroupNorm(x)) / Linear(x)                         K 320 / 640
+//   ln_qkv_tattn320_kernel     LayerNorm + to_q/k/v + attention over the 16 frames of a position               dim 320
+//   gn_silu_tconv_kernel       GroupNorm + SiLU + Conv3d (3,1,1) (+ identity) of a TemporalConvBlock            C 320 / 640
+// Common technique: volatile LDS fragment loads + empty `asm volatile` anchors pin the LDS prefetch distance and the
+// MFMA / VALU interleave (hipcc otherwise sinks every LDS read to just in front of its use); LDS-DMA pieces addressed by a
+// scalar base + per-lane offsets computed once; counted `s_waitcnt vmcnt` (gfx950 counts stores too).
+//
+// ---- Fused GEGLU FeedForward for dim = 320 (the UNet's level-0 transformers):
 //
 //   out[M, 320] = ( (X W1v^T + b1v) * gelu(X W1g^T + b1g) ) W2^T + b2 + residual        reference: FeedForward /
 //   GEGLU, lvdm/modules/attention.py:415-442, called from BasicTransformerBlock._forward :246
@@ -11,17 +21,21 @@
 // owns 128 rows; wave w owns rows [32 w, 32 w + 32) of it for the whole FeedForward:
 //   * X fragments of its rows stay in registers (20 x bf16x8 = 80 VGPRs), loaded once per tile straight from HBM;
 //   * the 1280 intermediate channels are walked in 40 chunks of 32. Per chunk the workgroup streams the 64 rows of W1
-//     (32 value + 32 gate rows x 320) and the 32 columns of W2 (320 x 32) through LDS by LDS-DMA (two-deep rings, 60 KB
-//     per chunk), one barrier per chunk;
-//   * phase 1: Pv, Pg = X W1v^T, X W1g^T   (2 accumulators, 40 MFMAs 32x32x16); GEGLU on the accumulators;
+//     (32 value + 32 gate rows x 320, two-deep ring) and the 32 columns of W2 (320 x 32, three-deep ring) through LDS by
+//     LDS-DMA (60 KB per chunk), one barrier per chunk;
+//   * phase 1: Pv, Pg = X W1v^T, X W1g^T   (2 accumulators, 40 MFMAs 32x32x16), hand-interleaved with the GEGLU
+//     arithmetic of the previous chunk;
 //   * phase 2: out += P W2c^T              (10 accumulators, 20 MFMAs) - P never leaves registers: with the swapped
 //     operand order a lane holds, for ITS row, 16 of the chunk's 32 channels, which is exactly a B-operand fragment
 //     pair once the k order is agreed on; the host packs W2 with that order inside every 32-channel chunk
-//     (position 16 s + 8 h + e  <->  channel 8 (2 s + e / 4) + 4 h + e % 4);
-//   * epilogue: + b2, bf16, + residual, row-major stores through a wave-private LDS patch.
-// Every weight fragment read from LDS feeds one MFMA (1 KB per MFMA: the LDS peak at the full MFMA rate) and a
-// workgroup streams W1 + W2 (2.4 MB) per 128 rows (the ~32 B/clk L2 -> LDS path at the full MFMA rate): both bounds sit
-// at ~100 %, the kernel is designed to run at about half of that.
+//     (position 16 s + 8 h + e  <->  channel 8 (2 s + e / 4) + 4 h + e % 4); the LDS-DMA pieces of the next chunks go
+//     out one behind each of its MFMAs;
+//   * epilogue: + b2, bf16, + residual, row-major stores through a wave-private LDS patch - or, PROJ, the result as B
+//     fragments of the transformer's proj_out.
+// Every weight fragment read from LDS feeds one MFMA (1 KB per MFMA = half the 256 B/clk LDS rate at the full MFMA rate)
+// and a workgroup streams W1 + W2 (2.4 MB) per 128 rows: with one wave per SIMD issuing the 60 MFMAs, ~260 vector
+// instructions and 15 LDS-DMA pieces of a chunk the kernel is instruction-issue-bound at about half the MFMA rate
+// (DESIGN.md section 3.2 has the per-phase stamps).
 #include "dc_common.h"
 #include "dcrafter_hip.h"
 #include <stdint.h>
