@@ -15,3 +15,11 @@ for (n_inst, rpi, C) in [(32, 9216, 320), (2, 147456, 320), (32, 2304, 640), (2,
     e1.record(); torch.cuda.synchronize()
     us = e0.elapsed_time(e1) / 20 * 1e3
     print(f"gn n_inst={n_inst} rows={rpi} C={C}: {us:.1f} us  {6.0 * n_inst * rpi * C / us / 1e6:.2f} TB/s (3 passes)", flush=True)
+    st = torch.empty(n_inst * 64, dtype=torch.float32, device=DEV)
+    for _ in range(3): ops.groupnorm_stats(x, st, groups=32, n_inst=n_inst, rows_per_inst=rpi, eps=1e-5)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(20): ops.groupnorm_stats(x, st, groups=32, n_inst=n_inst, rows_per_inst=rpi, eps=1e-5)
+    e1.record(); torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) / 20 * 1e3
+    print(f"   statistics only (partial + finalize): {us:.1f} us  {2.0 * n_inst * rpi * C / us / 1e6:.2f} TB/s (1 pass)", flush=True)
