@@ -61,6 +61,7 @@ SIGNATURES = {
     "dc_gn_silu_tconv3": (_I, [_P, _I, _I, _P, _P, _P, _I, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _P]),
     "dc_groupnorm_stats": (_I, [_P, _I, _I, _I, _I, _I, _F, _P, _P, _P]),
     "dc_gn_linear": (_I, [_P, _I, _I, _P, _P, _P, _I, _I, _P, _P, _P, _I, _I, _I, _P]),
+    "dc_flash_attn_set_mode": (_I, [_I, _F]),
     "dc_cross_attn_dual_d64": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _L, _L, _F, _F, _P]),
     "dc_temporal_attn_d64": (_I, [_P, _I, _P, _I, _I, _I, _I, _I, _F, _P]),
     "dc_gemv_small": (_I, [_P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),

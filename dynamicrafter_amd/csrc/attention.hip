@@ -13,6 +13,7 @@
 //   (clip, position, head)); reference: TemporalTransformer.forward attention.py:365-412 -> CrossAttention :81-144.
 #include "dc_common.h"
 #include "dcrafter_hip.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -390,6 +391,11 @@ extern "C" int dc_flash_attn_d64(const uint16_t* q, const uint16_t* k, const uin
     if (batch <= 0 || heads <= 0 || Lq <= 0 || Lk <= 0) return DC_ERR_SHAPE;
     if (ldq % 8 || ldk % 8 || ldv % 8 || ldo % 4) return DC_ERR_SHAPE;
     const float c = scale * 1.4426950408889634f;
+    // long self-attention: the one-wave-per-SIMD software-pipelined kernel (flash_pipe.hip); DC_FLASH_PIPE=0 keeps the
+    // two-waves-per-SIMD kernel below (same-box A/B)
+    static const bool use_pipe = [] { const char* e = getenv("DC_FLASH_PIPE"); return !(e && e[0] == '0'); }();
+    if (use_pipe && !accumulate && Lq >= 512 && Lk >= 256 && Lk % 64 == 0)
+        return dc_flash_pipe_launch(q, k, v, o, ldq, ldk, ldv, ldo, batch, heads, Lq, Lk, q_bstride, kv_bstride, c, stream);
     // two query blocks per wave (256 rows per workgroup) once there are enough rows and keys to pay for it
     const bool wide = Lq >= 512 && Lk >= 256;
     const int rows_wg = wide ? 2 * FA_BQ : FA_BQ;

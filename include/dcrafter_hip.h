@@ -94,6 +94,13 @@ int dc_flash_attn_d64(const uint16_t* q, const uint16_t* k, const uint16_t* v, u
                       int64_t q_bstride, int64_t kv_bstride, float scale, int accumulate, float acc_scale,
                       void* stream);
 
+/* Test / measurement hook for the long self-attention path of dc_flash_attn_d64 (Lq >= 512, Lk >= 256, Lk % 64 == 0, no
+ * accumulate: the one-wave-per-SIMD pipelined kernel, which takes the row maximum of the first 32 keys as the softmax shift
+ * and falls back to a running-max pass for a workgroup whose row sums leave [0, 2^100)). mode bit 0: run the running-max
+ * pass directly; thr (0..64, exp2 units): how far a score must exceed the running max before that pass rescales its state.
+ * Process-wide; default mode 0, thr 8. Returns 0 or DC_ERR_ARG. */
+int dc_flash_attn_set_mode(int mode, float thr);
+
 /* Temporal self-attention over T <= 16 frames, head_dim 64: for every (clip b, position p, head h) the T rows
  * (b, t, p) attend to each other. qkv rows are [q | k | v] (3*heads*64 wide, row stride ld).
  * replaces: CrossAttention.forward lvdm/modules/attention.py:81-144 as used by TemporalTransformer :365-412. */

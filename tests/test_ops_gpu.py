@@ -199,6 +199,102 @@ def test_flash_attn_fused_qkv_and_spike(ops):
     assert rel_l2(o, ref) < 6e-3
 
 
+# modes of the long self-attention kernel (dc_flash_attn_set_mode): (mode, thr) - default = the shift of the first half tile
+# kept for the whole pass; bit 0 = the running-max (tracking) pass run directly, with thr = 0 (rescale on every growth) and 8
+FLASH_MODES = [(0, 8.0), (1, 0.0), (1, 8.0)]
+
+
+@pytest.fixture
+def flash_mode(request):
+    from dynamicrafter_amd import _hip
+    mode, thr = request.param
+    assert _hip.lib().dc_flash_attn_set_mode(mode, thr) == 0
+    yield request.param
+    assert _hip.lib().dc_flash_attn_set_mode(0, 8.0) == 0
+
+
+@pytest.mark.parametrize("flash_mode", FLASH_MODES, indirect=True)
+@pytest.mark.parametrize("B,heads,Lq,Lk", [(2, 2, 1024, 1024), (1, 3, 768, 256), (1, 1, 1000, 512), (1, 2, 512, 2304),
+                                           (1, 1, 530, 128 + 64)])
+def test_flash_attn_long_self(ops, flash_mode, B, heads, Lq, Lk):
+    """Shapes that take the one-wave-per-SIMD software-pipelined kernel (flash_pipe.hip: Lq >= 512, Lk >= 256, Lk % 64 == 0)
+    and, last case, its boundary (Lk = 192 stays on the two-waves kernel). Ragged Lq exercises the clamped tail rows."""
+    Cc = heads * 64
+    q = bf(rnd(B, Lq, Cc, seed=11)); k = bf(rnd(B, Lk, Cc, seed=12)); v = bf(rnd(B, Lk, Cc, seed=13))
+    o = torch.zeros(B * Lq, Cc, dtype=torch.bfloat16, device=DEV)
+    ops.flash_attn(q.reshape(-1, Cc).to(DEV), k.reshape(-1, Cc).to(DEV), v.reshape(-1, Cc).to(DEV), o,
+                   batch=B, heads=heads, Lq=Lq, Lk=Lk, scale=0.125)
+    ref = _attn_ref(q.float(), k.float(), v.float(), heads, 0.125).reshape(-1, Cc)
+    assert rel_l2(o, ref) < 6e-3
+
+
+@pytest.mark.parametrize("flash_mode", FLASH_MODES, indirect=True)
+@pytest.mark.parametrize("spikes", [(5,), (40,), (70,), (100,), (130, 131), (511,), (480,), (449, 20), (200, 300, 400, 500),
+                                    tuple(range(0, 512, 37))])
+def test_flash_attn_long_self_running_max_jumps(ops, flash_mode, spikes):
+    """Keys with 6-14x the norm at chosen positions (first / second half tile, tile seams, the last half tiles, many at
+    once; growing sizes so that each raises the maximum again). The default pass keeps the shift of the first 32 keys (its P
+    then reach 2^40 and more: same relative precision); the tracking pass decides one half tile late whether a row's running
+    max grew and rescales O, the row sums and the already packed P of the pending half tile - the spikes force that path at
+    every stage of its pipeline."""
+    B, heads, L = 1, 2, 512
+    Cc = heads * 64
+    qkv = rnd(B * L, 3 * Cc, seed=21)
+    for n, pos in enumerate(spikes):
+        qkv[pos, Cc:2 * Cc] *= 6.0 + 0.6 * n
+    qkv = bf(qkv)
+    d = qkv.to(DEV)
+    o = torch.empty(B * L, Cc, dtype=torch.bfloat16, device=DEV)
+    ops.flash_attn(d[:, :Cc], d[:, Cc:2 * Cc], d[:, 2 * Cc:], o, batch=B, heads=heads, Lq=L, Lk=L, scale=0.125)
+    f = qkv.float().reshape(B, L, 3 * Cc)
+    ref = _attn_ref(f[..., :Cc], f[..., Cc:2 * Cc], f[..., 2 * Cc:], heads, 0.125).reshape(-1, Cc)
+    assert torch.isfinite(o.float()).all()
+    assert rel_l2(o, ref) < 6e-3
+
+
+@pytest.mark.parametrize("pos", [33, 100, 300, 511])
+def test_flash_attn_long_self_fallback_to_tracking_pass(ops, pos):
+    """A key far outside the range of the first 32: its scores exceed the first-half-tile maximum by > 2^100 in exp2 units
+    for most rows, the default pass's row sums overflow, and the workgroup must repeat its block with the running-max pass
+    (scores ~ +-150 nats: softmax is a one-hot on the spiked key for rows with a positive score, and the plain softmax
+    elsewhere). A second launch with ordinary data follows: the fallback leaves no state behind."""
+    B, heads, L = 1, 2, 512
+    Cc = heads * 64
+    qkv = rnd(B * L, 3 * Cc, seed=41)
+    qkv[pos, Cc:2 * Cc] *= 150.0
+    qkv = bf(qkv)
+    d = qkv.to(DEV)
+    o = torch.empty(B * L, Cc, dtype=torch.bfloat16, device=DEV)
+    ops.flash_attn(d[:, :Cc], d[:, Cc:2 * Cc], d[:, 2 * Cc:], o, batch=B, heads=heads, Lq=L, Lk=L, scale=0.125)
+    f = qkv.float().reshape(B, L, 3 * Cc)
+    ref = _attn_ref(f[..., :Cc], f[..., Cc:2 * Cc], f[..., 2 * Cc:], heads, 0.125).reshape(-1, Cc)
+    assert torch.isfinite(o.float()).all()
+    # scores of +-600 in exp2 units: the bf16 rounding of the pre-scaled Q (2^-9 relative) moves them by ~1 unit, which
+    # shows in the rows where the spiked key competes with another one (measured 8e-3; the two-waves kernel likewise)
+    assert rel_l2(o, ref) < 1.6e-2
+    qkv2 = bf(rnd(B * L, 3 * Cc, seed=42)).to(DEV)
+    ops.flash_attn(qkv2[:, :Cc], qkv2[:, Cc:2 * Cc], qkv2[:, 2 * Cc:], o, batch=B, heads=heads, Lq=L, Lk=L, scale=0.125)
+    f = qkv2.float().cpu().reshape(B, L, 3 * Cc)
+    ref = _attn_ref(f[..., :Cc], f[..., Cc:2 * Cc], f[..., 2 * Cc:], heads, 0.125).reshape(-1, Cc)
+    assert rel_l2(o, ref) < 6e-3
+
+
+def test_flash_attn_long_self_strided_batches(ops):
+    """q/k/v as column slices of one fused buffer with batch strides larger than L (the UNet's call shape)."""
+    B, heads, L, Lpad = 3, 5, 576, 600
+    Cc = heads * 64
+    qkv = bf(rnd(B * Lpad, 3 * Cc, seed=31))
+    d = qkv.to(DEV)
+    o = torch.zeros(B * Lpad, Cc, dtype=torch.bfloat16, device=DEV)
+    ops.flash_attn(d[:, :Cc], d[:, Cc:2 * Cc], d[:, 2 * Cc:], o, batch=B, heads=heads, Lq=L, Lk=L, scale=0.125,
+                   q_bstride=Lpad, kv_bstride=Lpad)
+    f = qkv.float().reshape(B, Lpad, 3 * Cc)[:, :L]
+    ref = _attn_ref(f[..., :Cc], f[..., Cc:2 * Cc], f[..., 2 * Cc:], heads, 0.125)
+    got = o.float().cpu().reshape(B, Lpad, Cc)
+    assert rel_l2(got[:, :L].reshape(-1, Cc), ref.reshape(-1, Cc)) < 6e-3
+    assert (got[:, L:] == 0).all()          # rows between the batch items are not touched
+
+
 @pytest.mark.parametrize("B,T,HW,heads", [(2, 16, 50, 5), (1, 16, 7, 8), (1, 4, 33, 2)])
 def test_temporal_attn(ops, B, T, HW, heads):
     Cc = heads * 64
