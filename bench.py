@@ -2,7 +2,9 @@
 """bench.py — DynamiCrafter denoising loop on MI355X: denoising-step latency and frames/s, 16 frames @ 576x1024.
 
     python bench.py --gpus N --steps K --warmup W
-    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+    N > 1: either under a launcher (python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...:
+    RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment) or directly - then bench.py starts that launcher itself as
+    a child process (before anything touches the GPU) and relays the one JSON line and the return code.
 
 Workload (BASELINE.json configs[2] / SURVEY §8d config 3): inference_1024_v1.0.yaml — latent 16x72x128, DDIM 50
 steps `uniform_trailing`, eta 1, CFG 7.5 (cond+uncond evaluated as one batch-2 UNet forward), guidance-rescale 0.7,
@@ -133,6 +135,35 @@ def oracle_forward_and_parity(model, res, x, cc, ctx, fs, t_step, e_hip, threads
     return dt, threads, rel, cos
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher: start `python -m torch.distributed.run --nproc-per-node N bench.py ...` as
+    a CHILD process and relay its one JSON line and its return code. This process has not touched the GPU (importing torch
+    does not), and it never replaces itself: a process that has initialised HIP must not exec on this pool."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:                       # a free rendezvous port on the loopback interface
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    log(f"--gpus {n}: launching {n} ranks: {' '.join(cmd)}")
+    child = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, env=dict(os.environ))
+    line = None
+    for ln in child.stdout:                           # ranks' progress goes to stderr (inherited); stdout carries the result
+        ln = ln.rstrip("\n")
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln
+        elif ln:
+            print(ln, file=sys.stderr, flush=True)
+    rc = child.wait()
+    if line is not None:
+        print(line, flush=True)
+    elif rc == 0:
+        rc = 1
+        log("the launched job printed no result line")
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -144,11 +175,13 @@ def main():
     ap.add_argument("--no-trace", action="store_true")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
+        raise SystemExit(f"--gpus {args.gpus} but the launcher started {world} ranks (WORLD_SIZE={world})")
     import torch.distributed as dist
     # DC_BENCH_BACKEND=gloo + DC_BENCH_SHARE_GPU=1 rehearse the N>1 code path on a one-GPU box (all ranks on cuda:0,
     # collectives on CPU tensors); the real launch uses RCCL ("nccl") with one GPU per rank.
@@ -279,6 +312,7 @@ def main():
         "value": round(fps, 4), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "bf16", "data": "synthetic (random-init weights, synthetic conditioning)",
+        "n_ranks_seen": dist.get_world_size() if world > 1 else 1, "backend": backend if world > 1 else None,
         "config": {"workload": f"inference_{res}_v1.0.yaml: 1 clip/GPU, 16 frames, latent {h}x{w}, DDIM 50 "
                                "uniform_trailing eta=1, CFG 7.5 batched (cond+uncond), guidance_rescale 0.7, "
                                "v-param+ZTSNR+dynamic rescale, hipGraph-captured step",

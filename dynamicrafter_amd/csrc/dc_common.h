@@ -3,6 +3,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <atomic>
 
 typedef uint16_t bf16_t;  // raw bf16 bits; all activations/weights in HBM are bf16 unless a kernel says fp32
 
@@ -96,5 +97,22 @@ void dc_note_variant(const char* name);
 int dc_flash_pipe_launch(const bf16_t* q, const bf16_t* k, const bf16_t* v, bf16_t* o, int ldq, int ldk, int ldv, int ldo,
                          int batch, int heads, int Lq, int Lk, int64_t q_bstride, int64_t kv_bstride, float c,
                          hipStream_t stream);
+
+// hipFuncAttributeMaxDynamicSharedMemorySize is a PER-DEVICE attribute: kernels with more than 64 KB of dynamic LDS are
+// configured once per device (bit mask; two host threads racing on the first call both set the attribute, which is harmless).
+struct DcLdsOnce {
+    std::atomic<unsigned long long> done{0};
+    int ensure(const void* fn, int bytes) {
+        int dev = 0;
+        hipError_t e = hipGetDevice(&dev);
+        if (e != hipSuccess) return (int)e;
+        const bool tracked = dev >= 0 && dev < 64;
+        if (tracked && (done.load(std::memory_order_acquire) >> dev & 1ull)) return 0;
+        e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+        if (e != hipSuccess) return (int)e;
+        if (tracked) done.fetch_or(1ull << dev, std::memory_order_release);
+        return 0;
+    }
+};
 
 #define DC_CHECK_LAUNCH() do { hipError_t e__ = hipGetLastError(); if (e__ != hipSuccess) return (int)e__; } while (0)

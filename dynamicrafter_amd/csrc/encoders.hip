@@ -222,13 +222,8 @@ extern "C" int dc_attn_small(const uint16_t* q, const uint16_t* k, const uint16_
     if ((ldq | ldk | ldv | ldo) % 2) return DC_ERR_SHAPE;
     const int64_t lds = dc_attn_small_lds_bytes(Lk, d);
     if (lds > 160 * 1024) return DC_ERR_SHAPE;
-    static int64_t configured = 0;
-    if (lds > configured) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_small_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return (int)e;
-        configured = 160 * 1024;
-    }
+    static DcLdsOnce lds_once;
+    if (const int e = lds_once.ensure(reinterpret_cast<const void*>(&attn_small_kernel), 160 * 1024)) return e;
     const int q_tiles = (Lq + AS_ROWS - 1) / AS_ROWS;
     hipLaunchKernelGGL(attn_small_kernel, dim3(B * heads * q_tiles), dim3(256), (size_t)lds, (hipStream_t)stream_, q, k, v, o,
                        ldq, ldk, ldv, ldo, heads, Lq, Lk, d, scale, causal, q_tiles);

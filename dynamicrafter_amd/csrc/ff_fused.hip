@@ -1185,13 +1185,8 @@ extern "C" int dc_ff_debug_stamps(unsigned long long* out, int reset) {
 
 template <bool LN, bool PROJ>
 static int launch_ff_fused(const FfParams& p, hipStream_t stream) {
-    static bool configured = false;
-    if (!configured) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ff_geglu_fused320_kernel<LN, PROJ>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, FF_LDS);
-        if (e != hipSuccess) return (int)e;
-        configured = true;
-    }
+    static DcLdsOnce lds_once;
+    if (const int e = lds_once.ensure(reinterpret_cast<const void*>(&ff_geglu_fused320_kernel<LN, PROJ>), FF_LDS)) return e;
     const int tiles = (p.M + FBM - 1) / FBM;
     hipLaunchKernelGGL((ff_geglu_fused320_kernel<LN, PROJ>), dim3(tiles < 256 ? tiles : 256), dim3(256), FF_LDS, stream, p);
     DC_CHECK_LAUNCH();
@@ -1235,13 +1230,8 @@ extern "C" int dc_ff_geglu_proj_fused320(const uint16_t* x, int ldx, const float
 
 template <int NORM, int KH>
 static int launch_norm_linear_t(const LlParams& p, dim3 grid, hipStream_t stream) {
-    static bool configured = false;
-    if (!configured) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&norm_linear_kernel<NORM, KH>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, ll_lds(KH));
-        if (e != hipSuccess) return (int)e;
-        configured = true;
-    }
+    static DcLdsOnce lds_once;
+    if (const int e = lds_once.ensure(reinterpret_cast<const void*>(&norm_linear_kernel<NORM, KH>), ll_lds(KH))) return e;
     hipLaunchKernelGGL((norm_linear_kernel<NORM, KH>), grid, dim3(256), ll_lds(KH), stream, p);
     DC_CHECK_LAUNCH();
     return 0;
@@ -1297,13 +1287,8 @@ extern "C" int dc_ln_qkv_temporal_attn320(const uint16_t* x, int ldx, const floa
     if (!x || !ln_gamma || !ln_beta || !wqkv || !out) return DC_ERR_ARG;
     if (B < 1 || T != 16 || HW < 8 || HW % 8 || ldx % 8 || ldo % 8) return DC_ERR_SHAPE;
     if (((uintptr_t)x | (uintptr_t)out | (uintptr_t)wqkv) % 16) return DC_ERR_SHAPE;
-    static bool configured = false;
-    if (!configured) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ln_qkv_tattn320_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, TA_LDS);
-        if (e != hipSuccess) return (int)e;
-        configured = true;
-    }
+    static DcLdsOnce lds_once;
+    if (const int e = lds_once.ensure(reinterpret_cast<const void*>(&ln_qkv_tattn320_kernel), TA_LDS)) return e;
     TaParams p;
     p.X = x; p.ldx = ldx; p.W = wqkv; p.O = out; p.ldo = ldo; p.ln_g = ln_gamma; p.ln_b = ln_beta; p.ln_eps = ln_eps;
     p.HW = HW; p.c = scale * 1.4426950408889634f;
@@ -1314,13 +1299,8 @@ extern "C" int dc_ln_qkv_temporal_attn320(const uint16_t* x, int ldx, const floa
 
 template <int KH, bool RES>
 static int launch_gn_silu_tconv(const TcParams& p, dim3 grid, hipStream_t stream) {
-    static bool configured = false;
-    if (!configured) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gn_silu_tconv_kernel<KH, RES>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, ll_lds(KH));
-        if (e != hipSuccess) return (int)e;
-        configured = true;
-    }
+    static DcLdsOnce lds_once;
+    if (const int e = lds_once.ensure(reinterpret_cast<const void*>(&gn_silu_tconv_kernel<KH, RES>), ll_lds(KH))) return e;
     hipLaunchKernelGGL((gn_silu_tconv_kernel<KH, RES>), grid, dim3(256), ll_lds(KH), stream, p);
     DC_CHECK_LAUNCH();
     return 0;

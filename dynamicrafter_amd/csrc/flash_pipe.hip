@@ -3,39 +3,40 @@
 //   o = softmax(q k^T * scale) v        reference: CrossAttention.forward, lvdm/modules/attention.py:101-125
 //
 // The two-waves-per-SIMD kernel of attention.hip spends ~1750 cycles per (64 queries x 64 keys) of a wave where the matrix
-// pipe needs 1024: its two waves reach the exp / pack / max stream together. Here a workgroup is 4 waves = 256 query rows,
-// a wave owns 64 rows (two 32-row blocks) and the whole register file, and the vector work of one 32-key HALF TILE is
-// placed by hand in the gaps between the MFMAs of its neighbours:
+// pipe needs 1024: its two waves reach the exp / pack / max stream together. Here a workgroup is 4 waves, a wave owns QB
+// 32-row query blocks (QB = 3: 384 rows per workgroup) and the whole register file, and the vector work of one 32-key HALF
+// TILE is placed by hand in the gaps between the MFMAs of its neighbours:
 //
-//   step h (16 MFMAs):   gaps 0..7   S(h+2) = K(h+2) (cQ)^T - m     [QK^T of the half tile two ahead]
-//                        gaps 8..15  O^T  += V(h)^T P(h)^T          [PV of the current half tile]
-//                        gaps 16..19 l += 1^T P(h)^T                [row sums on the matrix pipe]
-//   beside them:         gaps 0..15  P(h+1) = exp2(S(h+1)), bf16 pack                   (2 v_exp_f32 + 1 pack per gap)
-//                        gaps 16..19 the LDS fragment requests of step h+1              (3 per gap)
-//                        gaps 8..11  one 16-byte global load (even steps) / LDS store (odd steps) of the K/V ring each
+//   step h (10 QB MFMAs): gaps 0..4QB-1    S(h+2) = K(h+2) (cQ)^T        [QK^T of the half tile two ahead]
+//                         gaps 4QB..8QB-1  O^T  += V(h)^T P(h)^T         [PV of the current half tile]
+//                         gaps 8QB..10QB-1 l += 1^T P(h)^T               [row sums on the matrix pipe, a ones fragment as A]
+//   beside them:          gaps 0..8QB-1    P(h+1) = exp2(S(h+1)), bf16 pack            (2 v_exp_f32 + 1 pack per gap)
+//                         gaps 8QB..       every memory instruction: the 12 LDS fragment requests of step h+1 and, in even
+//                                          steps, the 4 LDS stores + 4 global loads of the K/V ring
 //
-// Issue slots are what bounds this kernel (and the two-waves one: both measured 1750 cycles of issue per 64-key tile), so
-// the vector stream is kept to what softmax cannot do without - one v_exp_f32 per score, one pack per pair:
-//   * NO RUNNING MAX in the main pass. m is the row maximum of the FIRST 32 keys and stays: softmax is invariant under the
-//     shift, exp2(s - m) keeps its relative precision anywhere in the fp32 / bf16 exponent range, and fp32 sums of 9216
-//     terms are safe while every term is below 2^100. A row whose later scores exceed its first-half-tile maximum by more
-//     than ~100 (69 nats) shows up as a row sum that is not < 2^100 (or NaN): then the whole workgroup repeats its block
-//     with the tracking pass (TRACK: v_max3 chains in gaps 10..15, the rescale decision one half tile late, threshold
-//     `thr`) - the classical online softmax, kept as the fallback that makes the kernel total.
-//   * row sums as 4 more MFMAs per step (a ones fragment as A operand) instead of 32 v_add_f32: the matrix pipe has the
-//     room (40 of ~44 gaps' worth per tile), the issue port does not.
+// What bounds it is the issue port of the one wave (tools/ubench/gapcost.hip: an MFMA gap hides 2 v_exp_f32 + 1 pack, 33.5
+// clocks; two more v_add_f32 make it 41; tools/flash_variants.sh + flash_stamps.py on this kernel: a memory instruction inside
+// an exp gap costs ~40 clocks, in a bare MFMA gap ~10), so the vector stream is kept to what softmax cannot do without - one
+// v_exp_f32 per score, one pack per pair - and everything else sits in the row-sum gaps:
+//   * NO RUNNING MAX in the main pass: P = exp2(s) with the shift m = 0. Softmax is invariant under the shift, exp2 keeps its
+//     relative precision anywhere in the fp32 / bf16 exponent range, and fp32 sums of 9216 terms are safe while every term
+//     is below 2^100. A row whose scores leave +-100 (69 nats) shows up as a row sum outside [2^-100, 2^100) (or NaN): then
+//     the whole workgroup repeats its block with the tracking pass (TRACK: v_max3 chains beside the PV MFMAs, the rescale
+//     decision one half tile late, threshold `thr`) - the classical online softmax, kept as the fallback that makes the
+//     kernel total.
+//   * row sums as 2QB more MFMAs per step instead of 16QB v_add_f32: the matrix pipe has the room, the issue port does not;
+//     their gaps carry no vector work and are where the memory instructions go.
+//   * QB = 3: the 12 fragment requests and 8 ring instructions of a tile are shared by 1.5x the MFMAs.
 //
-// Every instruction of that stream is an `asm volatile` statement: hipcc allocates the registers and counts the LDS
+// Every instruction of the stream is an `asm volatile` statement: hipcc allocates the registers and counts the LDS / buffer
 // loads, the order is the source order (volatile statements are not reordered among themselves). Distances that the
-// hardware does not interlock and hipcc does not pad inside asm are kept by construction: an MFMA result is first read by
-// a vector instruction >= 2 gaps later; a v_exp_f32 result is consumed >= 2 instructions later; P is packed a step before
-// the MFMA that reads it; the rare path ends in s_nop padding.
-// S lives in architectural VGPRs (the exp / max stream reads it), O and Q in the accumulator file, -m as two 16-register
-// tuples that are the C operand of the first MFMA of a score chain (no per-tile accumulator initialisation).
+// hardware does not interlock and hipcc does not pad inside asm are kept by construction: an MFMA result is first read by a
+// vector instruction >= 2 gaps later; a v_exp_f32 result is consumed >= 2 instructions later; P is packed a step before the
+// MFMA that reads it; compiler-generated code that touches MFMA results sits behind a padding statement that takes them as
+// in/out operands (hipcc had hoisted v_accvgpr_read of the row sums above a plain s_nop statement).
+// S lives in architectural VGPRs (the exp / max stream reads it), O, l and Q in the accumulator file.
 // K / V tiles of 64 keys: global -> registers -> LDS ring of 4 stages, one barrier per tile; K fragments by ds_read_b128
-// (XOR-swizzled rows), V^T fragments by ds_read_b64_tr_b16. Measured (tools/flash_stamp_variants.sh, shader clocks per 64-key
-// tile): with the staging as one block at the end of a tile and the fragment requests inside the exp gaps 2040, of which
-// 435 the staging block + its drain and barrier and 245 the requests; MFMAs + vector stream alone 1350 (40 MFMAs = 1280).
+// (XOR-swizzled rows), V^T fragments by ds_read_b64_tr_b16.
 #include "dc_common.h"
 #include "dcrafter_hip.h"
 #include <type_traits>
@@ -53,7 +54,6 @@ constexpr int FP_VBYTES = 64 * FP_VLD;
 constexpr int FP_STAGE = FP_KBYTES + FP_VBYTES;     // 20 KB
 constexpr int FP_NSTAGE = 4;
 constexpr int FP_LDS = FP_NSTAGE * FP_STAGE;        // 80 KB
-constexpr int FP_ROWS = 256;                        // query rows per workgroup
 
 template <int V> using ic = std::integral_constant<int, V>;
 
@@ -71,18 +71,39 @@ __device__ unsigned long long g_fp_stamps[4];
 #define FP_ADD(acc, x) asm volatile("v_add_f32 %0, %0, %1" : "+v"(acc) : "v"(x))
 #define FP_CVT(dst, lo, hi) asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(dst) : "v"(lo), "v"(hi))
 #define FP_MAX3(acc, a, b) asm volatile("v_max3_f32 %0, %0, %1, %2" : "+v"(acc) : "v"(a), "v"(b))
-// S chain (D, C in VGPRs; B = Q fragment in the accumulator file)
-#define FP_MFMA_S0(d, a, b, c) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %3" : "=&v"(d) : "v"(a), "a"(b), "v"(c))
-#define FP_MFMA_SZ(d, a, b) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(d) : "v"(a), "a"(b))
-#define FP_MFMA_S(d, a, b) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(d) : "v"(a), "a"(b))
-// O and row-sum chains (D = C in the accumulator file)
+// S chain (D, C in VGPRs; A = K fragment and B = Q fragment in the accumulator file: the LDS reads land there directly, the
+// architectural VGPRs are kept for what the vector ALU touches - S, P, addresses)
+#define FP_MFMA_SZ(d, a, b) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(d) : "a"(a), "a"(b))
+#define FP_MFMA_S(d, a, b) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(d) : "a"(a), "a"(b))
+// O and row-sum chains (D = C in the accumulator file, B = P in VGPRs). The V^T fragments stay in VGPRs: they are assembled
+// from two transposed reads, and as "a" operands hipcc put the v_accvgpr_write copies right in front of the MFMA that reads
+// them - a hazard it does not pad for an asm statement (wrong results, no fault)
 #define FP_MFMA_O(d, a, b) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(d) : "v"(a), "v"(b))
+#define FP_MFMA_L(d, a, b) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(d) : "a"(a), "v"(b))
 
+
+// padding statement that takes the accumulators of all query blocks as in/out operands (see the header)
+template <int QB>
+__device__ __forceinline__ void fp_settle(f32x16_t (&O)[QB][2], f32x16_t (&L)[QB]) {
+    if constexpr (QB == 2)
+        asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7" : "+a"(O[0][0]), "+a"(O[0][1]), "+a"(O[1][0]), "+a"(O[1][1]), "+a"(L[0]),
+                     "+a"(L[1]));
+    else
+        asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7" : "+a"(O[0][0]), "+a"(O[0][1]), "+a"(O[1][0]), "+a"(O[1][1]), "+a"(O[2][0]),
+                     "+a"(O[2][1]), "+a"(L[0]), "+a"(L[1]), "+a"(L[2]));
+}
+
+template <int QB>
 __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1)))
 void flash_attn_d64_pipe_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,
                                 bf16_t* __restrict__ o, int ldq, int ldk, int ldv, int ldo, int heads, int Lq, int Lk,
                                 int64_t q_bstride, int64_t kv_bstride, float c /* scale*log2(e) */, int q_tiles, float thr,
                                 int force_track) {
+    static_assert(QB == 2 || QB == 3, "query blocks per wave");
+    constexpr int ROWS = 128 * QB;        // query rows per workgroup
+    constexpr int NQK = 4 * QB;           // score MFMAs of a step (gaps 0 .. NQK-1)
+    constexpr int NEX = 8 * QB;           // gaps that carry an exp pair; gaps NQK .. NEX-1 hold the PV MFMAs
+    constexpr int NL = 2 * QB;            // row-sum MFMAs (gaps NEX .. NEX+NL-1)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -100,17 +121,17 @@ void flash_attn_d64_pipe_kernel(const bf16_t* __restrict__ q, const bf16_t* __re
     const bf16_t* vb = v + (size_t)b * kv_bstride * ldv + head * 64;
     bf16_t* ob = o + (size_t)b * q_bstride * ldo + head * 64;
 
-    // ---- Q fragments (B operand of S^T = K (cQ)^T): lane (r, h) holds cQ[row][16kk + 8h .. +7] of its two query blocks
-    int qrow[2];
-    bf16x8_t Q[2][4];
+    // ---- Q fragments (B operand of S^T = K (cQ)^T): lane (r, h) holds cQ[row][16kk + 8h .. +7] of its query blocks
+    int qrow[QB];
+    bf16x8_t Q[QB][4];
 #pragma unroll
-    for (int x = 0; x < 2; ++x) {
-        qrow[x] = qt * FP_ROWS + (wave * 2 + x) * 32 + fr;
+    for (int x = 0; x < QB; ++x) {
+        qrow[x] = qt * ROWS + (wave * QB + x) * 32 + fr;
         const int qc = qrow[x] < Lq ? qrow[x] : Lq - 1;
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
             // Q is pre-multiplied by scale*log2(e) (one more bf16 rounding of Q, the size of the one it already has): the
-            // scores leave the MFMA in exp2 units and, with the accumulator started at -m, as s - m
+            // scores leave the MFMA in exp2 units
             const u32x4_t raw = *reinterpret_cast<const u32x4_t*>(qb + (size_t)qc * ldq + kk * 16 + fh * 8);
             u32x4_t sc;
 #pragma unroll
@@ -121,34 +142,33 @@ void flash_attn_d64_pipe_kernel(const bf16_t* __restrict__ q, const bf16_t* __re
         }
     }
 
-    // ---- staging: 64 rows x 8 chunks of 16 B per tensor and tile, 2 rows per thread; uniform tile base + per-lane offsets
-    const int chunk = tid & 7, srow = tid >> 3;
-    const int nt = Lk >> 6;
-    u32x4_t kreg[2], vreg[2];
-    unsigned kgo[2], vgo[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        kgo[i] = (unsigned)((srow + 32 * i) * ldk + chunk * 8) * 2u;
-        vgo[i] = (unsigned)((srow + 32 * i) * ldv + chunk * 8) * 2u;
-    }
+    // ---- staging: 64 rows x 8 chunks of 16 B per tensor and tile, 2 rows per thread.
     // piece j of a tile: 0 = K rows 0..31, 1 = V rows 0..31, 2 = K rows 32..63, 3 = V rows 32..63 (one 16-byte load / store each).
     // Buffer loads: descriptor of the (batch, head) slice in SGPRs, the lane's offset in a VGPR that never changes, the tile's
     // offset in an SGPR - one instruction per piece, no per-lane address arithmetic
+    const int chunk = tid & 7, srow = tid >> 3;
+    const int nt = Lk >> 6;
+    u32x4_t kreg[2], vreg[2];
+    const unsigned kgo = (unsigned)(srow * ldk + chunk * 8) * 2u, vgo = (unsigned)(srow * ldv + chunk * 8) * 2u;
     const __amdgpu_buffer_rsrc_t krs = __builtin_amdgcn_make_buffer_rsrc((void*)kb, 0, 0x7fffffff, 0x00020000);
     const __amdgpu_buffer_rsrc_t vrs = __builtin_amdgcn_make_buffer_rsrc((void*)vb, 0, 0x7fffffff, 0x00020000);
     auto load_piece = [&](int t, int j) __attribute__((always_inline)) {
         t = t < nt ? t : nt - 1;                      // past the end: the last tile again (finite data, never used)
+        const int row0 = t * 64 + (j >> 1) * 32;      // rows 32.. of the tile through the scalar offset
 #ifndef FP_DBG_NOLOAD
-        if (j & 1) vreg[j >> 1] = __builtin_amdgcn_raw_buffer_load_b128(vrs, vgo[j >> 1], t * 128 * ldv, 0);
-        else kreg[j >> 1] = __builtin_amdgcn_raw_buffer_load_b128(krs, kgo[j >> 1], t * 128 * ldk, 0);
+        if (j & 1) vreg[j >> 1] = __builtin_amdgcn_raw_buffer_load_b128(vrs, vgo, row0 * 2 * ldv, 0);
+        else kreg[j >> 1] = __builtin_amdgcn_raw_buffer_load_b128(krs, kgo, row0 * 2 * ldk, 0);
 #endif
     };
+    // per-lane LDS store offsets inside a stage (K rows XOR-swizzled by 16-byte chunk - the swizzle of row r + 32 is that of row
+    // r -, V rows padded to FP_VLD): rows 32.. are immediates
+    const unsigned kso = (unsigned)(srow * 128 + ((chunk ^ ((srow >> 1) & 7)) << 4));
+    const unsigned vso = (unsigned)(FP_KBYTES + srow * FP_VLD + chunk * 16);
     auto store_piece = [&](int stage, int j) __attribute__((always_inline)) {
         char* sk = smem + stage * FP_STAGE;
-        const int r = srow + 32 * (j >> 1);
 #ifndef FP_DBG_NOSTORE
-        if (j & 1) *reinterpret_cast<u32x4_t*>(sk + FP_KBYTES + r * FP_VLD + chunk * 16) = vreg[j >> 1];
-        else *reinterpret_cast<u32x4_t*>(sk + r * 128 + ((chunk ^ ((r >> 1) & 7)) << 4)) = kreg[j >> 1];
+        if (j & 1) *reinterpret_cast<u32x4_t*>(sk + vso + (j >> 1) * 32 * FP_VLD) = vreg[j >> 1];
+        else *reinterpret_cast<u32x4_t*>(sk + kso + (j >> 1) * 4096) = kreg[j >> 1];
 #endif
     };
 
@@ -164,17 +184,16 @@ void flash_attn_d64_pipe_kernel(const bf16_t* __restrict__ q, const bf16_t* __re
     const unsigned lds0 = (unsigned)(uintptr_t)((const lds_char_t*)smem);
 
     // ---- state
-    f32x16_t S[2][2];          // [half-tile parity][query block]: scores minus m, exp2 units
-    u32x4_t P[2][2][2];        // [half-tile parity][query block][k step]: exp2(S) packed to bf16 = B operand of the PV MFMAs
-    f32x16_t O[2][2];          // [query block][32-wide slice of d]
-    f32x16_t L[2];             // row sums (every register of a lane holds the sum of its query row)
-    f32x16_t NM[2];            // -m[x] in all 16 registers: C operand of the first MFMA of a score chain
-    float m_run[2], mx[2][2];  // mx: two independent v_max3 chains per query block (tracking pass)
+    f32x16_t S[2][QB];         // [half-tile parity][query block]: scores (minus m in the tracking pass), exp2 units
+    u32x4_t P[2][QB][2];       // [half-tile parity][query block][k step]: exp2(S) packed to bf16 = B operand of the PV MFMAs
+    f32x16_t O[QB][2];         // [query block][32-wide slice of d]
+    f32x16_t L[QB];            // row sums (every register of a lane holds the sum of its query row)
+    float m_run[QB], mx[QB][2];   // tracking pass: running max; two independent v_max3 chains per query block
     float mm = 0.f;
     bf16x8_t Kf[4];
     bf16x8_t Vf[2][2];
     u32x4_t ONES = {0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
-    asm volatile("" : "+v"(ONES));
+    asm volatile("" : "+a"(ONES));
 
     // fragment reads take complete per-lane LDS addresses (kept in registers, advanced once per tile; the parity of the half
     // tile and the fragment inside the step are immediates)
@@ -182,30 +201,29 @@ void flash_attn_d64_pipe_kernel(const bf16_t* __restrict__ q, const bf16_t* __re
         Kf[slot] = *(lds_vfrag_t*)((const lds_char_t*)(uintptr_t)addr + par * 4096);
     };
     bf16x4_t vlo;
-    auto rd_v_lo = [&](int ks, int db, unsigned addr, int par) __attribute__((always_inline)) {
+    auto rd_v_half = [&](int idx, unsigned addr, int par) __attribute__((always_inline)) {      // idx = 4 ks + 2 db + (0 lo, 1 hi)
+        const int ks = idx >> 2, db = (idx >> 1) & 1;
         const lds_char_t* vp = (const lds_char_t*)(uintptr_t)addr + (par * 32 + 16 * ks) * FP_VLD + db * 64;
-        vlo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_bf16x4_t*)(vp));
-    };
-    auto rd_v_hi = [&](int ks, int db, unsigned addr, int par) __attribute__((always_inline)) {
-        const lds_char_t* vp = (const lds_char_t*)(uintptr_t)addr + (par * 32 + 16 * ks) * FP_VLD + db * 64;
-        const bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_bf16x4_t*)(vp + 8 * FP_VLD));
-        bf16x8_t f;
-        f[0] = vlo[0]; f[1] = vlo[1]; f[2] = vlo[2]; f[3] = vlo[3];
-        f[4] = hi[0]; f[5] = hi[1]; f[6] = hi[2]; f[7] = hi[3];
-        Vf[ks][db] = f;
+        if (!(idx & 1)) {
+            vlo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_bf16x4_t*)(vp));
+        } else {
+            const bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_bf16x4_t*)(vp + 8 * FP_VLD));
+            bf16x8_t f;
+            f[0] = vlo[0]; f[1] = vlo[1]; f[2] = vlo[2]; f[3] = vlo[3];
+            f[4] = hi[0]; f[5] = hi[1]; f[6] = hi[2]; f[7] = hi[3];
+            Vf[ks][db] = f;
+        }
     };
 
-    // first = the row maximum of the first half tile becomes m. Otherwise (tracking pass only): some row's running max
-    // grew by more than thr - everything still at the old max (O, the row sums, the packed P of the half tile whose PV is
-    // pending) is multiplied by 2^-step exactly once, the scores of the half tile that raised the max are shifted by it
-    auto rescale = [&](f32x16_t (&Sp)[2], u32x4_t (&Pp)[2][2], bool first) __attribute__((always_inline)) {
-        // asm MFMA results (O, L, S) -> vector reads below: the padding statement takes the accumulators as in/out operands, so
-        // hipcc cannot read them above it (it had hoisted the v_accvgpr_read of L out of the branch, right behind the row-sum
-        // MFMAs - garbage on every rescale)
-        asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7" : "+a"(O[0][0]), "+a"(O[0][1]), "+a"(O[1][0]), "+a"(O[1][1]),
-                     "+a"(L[0]), "+a"(L[1]), "+v"(Sp[0]), "+v"(Sp[1]));
+    // Tracking pass only. first = the row maximum of the first half tile becomes m. Otherwise some row's running max grew by
+    // more than thr: everything still at the old max (O, the row sums, the packed P of the half tile whose PV is pending) is
+    // multiplied by 2^-step exactly once, the scores of the half tile that raised the max are shifted by it
+    auto rescale = [&](f32x16_t (&Sp)[QB], u32x4_t (&Pp)[QB][2], bool first) __attribute__((always_inline)) {
+        fp_settle<QB>(O, L);                                      // asm MFMA results -> vector reads below
 #pragma unroll
-        for (int x = 0; x < 2; ++x) {
+        for (int x = 0; x < QB; ++x) asm volatile("" : "+v"(Sp[x]));
+#pragma unroll
+        for (int x = 0; x < QB; ++x) {
             float r = fmaxf(mx[x][0], mx[x][1]);
             r = fmaxf(r, __shfl_xor(r, 32, 64));
             const float step = first ? r : fmaxf(r, 0.f);
@@ -223,107 +241,104 @@ void flash_attn_d64_pipe_kernel(const bf16_t* __restrict__ q, const bf16_t* __re
                     }
             }
 #pragma unroll
-            for (int e = 0; e < 16; ++e) { Sp[x][e] -= step; NM[x][e] = -m_run[x]; }
+            for (int e = 0; e < 16; ++e) Sp[x][e] -= step;
         }
-        // vector writes above -> asm MFMA operands below
-        asm volatile("s_nop 7\n\ts_nop 7" : "+a"(O[0][0]), "+a"(O[0][1]), "+a"(O[1][0]), "+a"(O[1][1]), "+a"(L[0]), "+a"(L[1]),
-                     "+v"(Sp[0]), "+v"(Sp[1]), "+v"(NM[0]), "+v"(NM[1]), "+v"(Pp[0][0]), "+v"(Pp[0][1]), "+v"(Pp[1][0]),
-                     "+v"(Pp[1][1]));
+        fp_settle<QB>(O, L);                                      // vector writes above -> asm MFMA operands below
+#pragma unroll
+        for (int x = 0; x < QB; ++x) asm volatile("" : "+v"(Sp[x]), "+v"(Pp[x][0]), "+v"(Pp[x][1]));
     };
 
-    // One half-tile step = 16 gaps, + 4 for the row-sum MFMAs when it has PV. Every LDS fragment of a step is requested in the
-    // last four gaps of the step BEFORE it (in steps with PV those are the row-sum gaps, which carry no vector work): kn =
-    // addresses of the next step's four K fragments, vn = its V^T fragment base, NK / NV = does the next step need them.
-    // The ring, per tile iteration T (steps 2T, 2T+1; tile X is last requested in step 2X, first in step 2X-3):
-    //   MEM 1 (step 2T):   gaps 4..7 the four 16-byte LDS stores of tile T+2 (loaded an iteration ago: ~1500 cycles of cover
-    //                      for the loads; a half-iteration was not enough, the stores waited ~400 cycles per tile) into the
-    //                      stage of tile T-2; gaps 8..11 the four global loads of tile T+3 into the same staging registers;
-    //   MEM 2 (step 2T+1): in front of gap 8 `s_waitcnt lgkmcnt(0)` + the workgroup barrier (the step's own requests went out
-    //                      >= 8 gaps earlier, so the wait is free): behind it every wave's stores of tile T+2 are complete and
-    //                      its requests of tile T-1 have returned. Tile T+2 is first requested in gaps 16..19 of this step.
+    // One half-tile step. TR: tracking pass (score chains start at -m, v_max3 chains beside the PV MFMAs, decision DEC at the
+    // top). The memory instructions sit in the last NL gaps (the row-sum gaps when the step has PV), spread evenly in this
+    // order: the next step's four K fragments (kn: their addresses, NK: needed) and eight V^T fragment halves (vn, NV), then,
+    // RING 1 (even steps of the loop), the four LDS stores of tile T+2 (loaded an iteration ago) into the stage of tile T-2 and
+    // the four global loads of tile T+3 into the same staging registers. RING 2 (odd steps): `s_waitcnt lgkmcnt(0)` + the
+    // workgroup barrier in front of those gaps (everything the wave has requested has long returned, so the wait is free):
+    // behind it every wave's stores of tile T+2 are complete - it is first requested right there - and its requests of tile
+    // T-1 have returned.
     // In-gap order: the MFMA, this gap's two v_exp_f32, then the pack of the PREVIOUS gap's exponentials, v_max3 in between -
     // no statement directly follows one that produced an operand of it (hipcc pads such pairs of asm statements).
-    auto step = [&](auto PAR_, auto DEC_, auto QK_, auto ZERO_, auto MX_, auto EX_, auto PV_, auto NK_, auto NV_, auto MEM_,
-                    const unsigned (&kn)[4], int knpar, unsigned vn, int vnpar, int tile, int stage, unsigned vc = 0) __attribute__((always_inline)) {
-        constexpr int PAR = decltype(PAR_)::value, MEM = decltype(MEM_)::value;
-        constexpr bool DEC = decltype(DEC_)::value, QK = decltype(QK_)::value, ZERO = decltype(ZERO_)::value;
+    auto step = [&](auto PAR_, auto TR_, auto DEC_, auto QK_, auto MX_, auto EX_, auto PV_, auto NK_, auto NV_, auto RING_,
+                    const unsigned (&kn)[4], int knpar, unsigned vn, int vnpar, int tile, int stage) __attribute__((always_inline)) {
+        constexpr int PAR = decltype(PAR_)::value, RING = decltype(RING_)::value;
+        constexpr bool TR = decltype(TR_)::value, DEC = decltype(DEC_)::value, QK = decltype(QK_)::value;
         constexpr bool MX = decltype(MX_)::value, EX = decltype(EX_)::value, PV = decltype(PV_)::value;
         constexpr bool NK = decltype(NK_)::value, NV = decltype(NV_)::value;
-        constexpr int NG = PV ? 20 : 16;
-        f32x16_t (&Sw)[2] = S[PAR];
-        f32x16_t (&Sr)[2] = S[PAR ^ 1];
-        u32x4_t (&Pr)[2][2] = P[PAR];
-        u32x4_t (&Pw)[2][2] = P[PAR ^ 1];
+        constexpr int NG = PV ? NEX + NL : NEX;
+        constexpr int NSLOT = (NK ? 4 : 0) + (NV ? 8 : 0) + (RING == 1 ? 8 : 0);
+        f32x16_t (&Sw)[QB] = S[PAR];
+        f32x16_t (&Sr)[QB] = S[PAR ^ 1];
+        u32x4_t (&Pr)[QB][2] = P[PAR];
+        u32x4_t (&Pw)[QB][2] = P[PAR ^ 1];
         if constexpr (DEC) {
             if (__builtin_amdgcn_ballot_w64(mm > thr) != 0) rescale(Sr, Pr, false);
         }
-        if constexpr (MX) { mx[0][0] = -3.0e38f; mx[0][1] = -3.0e38f; mx[1][0] = -3.0e38f; mx[1][1] = -3.0e38f; }
-        float pa[16], pb[16];
+        if constexpr (MX) {
+#pragma unroll
+            for (int x = 0; x < QB; ++x) { mx[x][0] = -3.0e38f; mx[x][1] = -3.0e38f; }
+        }
+        float pa[NEX], pb[NEX];
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
             // ---- memory instructions of this gap
+            const int j = g - (NG - NL);              // 0 .. NL-1 in the last NL gaps
 #ifndef FP_DBG_NOBAR
-            if constexpr (MEM == 2) { if (g == 8) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+            if constexpr (RING == 2) { if (j == 0) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 #endif
-#ifndef FP_DBG_NOSTAGE
-            if constexpr (MEM == 1) {
-                if (g >= 4 && g < 8) store_piece(stage, g - 4);
-                if (g >= 8 && g < 12) load_piece(tile, g - 8);
-            }
-#endif
+            if constexpr (NSLOT > 0) {
+#pragma unroll
+                for (int sl = 0; sl < NSLOT; ++sl) {
+                    if (j < 0 || sl * NL / NSLOT != j) continue;
+                    int idx = sl;
 #ifndef FP_DBG_NOLDS
-            {
-                const int j = g - (NG - 4);          // 0..3 in the last four gaps: three fragment reads each
-                if constexpr (NK) {
-                    if (j == 0) { rd_k(0, kn[0], knpar); rd_k(1, kn[1], knpar); rd_k(2, kn[2], knpar); }
-                    if (j == 1) rd_k(3, kn[3], knpar);
-                }
-#ifndef FP_V_IN_STEP
-                if constexpr (NV) {
-                    if (j == 1) { rd_v_lo(0, 0, vn, vnpar); rd_v_hi(0, 0, vn, vnpar); }
-                    if (j == 2) { rd_v_lo(0, 1, vn, vnpar); rd_v_hi(0, 1, vn, vnpar); rd_v_lo(1, 0, vn, vnpar); }
-                    if (j == 3) { rd_v_hi(1, 0, vn, vnpar); rd_v_lo(1, 1, vn, vnpar); rd_v_hi(1, 1, vn, vnpar); }
-                }
-#else
-                if constexpr (PV) {           // tool build: the step's own V^T fragments in its gaps 0..3
-                    if (g == 0) { rd_v_lo(0, 0, vc, PAR); rd_v_hi(0, 0, vc, PAR); }
-                    if (g == 1) { rd_v_lo(0, 1, vc, PAR); rd_v_hi(0, 1, vc, PAR); }
-                    if (g == 2) { rd_v_lo(1, 0, vc, PAR); rd_v_hi(1, 0, vc, PAR); }
-                    if (g == 3) { rd_v_lo(1, 1, vc, PAR); rd_v_hi(1, 1, vc, PAR); }
-                }
+                    if (NK && idx < 4) rd_k(idx, kn[idx], knpar);
 #endif
+                    if (NK) idx -= 4;
+#ifndef FP_DBG_NOLDS
+                    if (NV && idx >= 0 && idx < 8) rd_v_half(idx, vn, vnpar);
+#endif
+                    if (NV) idx -= 8;
+#ifndef FP_DBG_NOSTAGE
+                    if (RING == 1 && idx >= 0 && idx < 4) store_piece(stage, idx);
+                    if (RING == 1 && idx >= 4 && idx < 8) load_piece(tile, idx - 4);
+#endif
+                }
             }
-#endif
             // ---- the matrix instruction of this gap
-            if (g < 8) {
+            if (g < NQK) {
                 if constexpr (QK) {
-                    const int kk = g >> 1, x = g & 1;
+                    const int kk = g / QB, x = g % QB;
                     if (kk == 0) {
-                        if constexpr (ZERO) FP_MFMA_SZ(Sw[x], Kf[0], Q[x][0]);
-                        else FP_MFMA_S0(Sw[x], Kf[0], Q[x][0], NM[x]);
+                        if constexpr (TR) {               // the chain starts at -m: 16 moves (the fallback pass may be slow)
+#pragma unroll
+                            for (int e = 0; e < 16; ++e) Sw[x][e] = -m_run[x];
+                            asm volatile("s_nop 1" : "+v"(Sw[x]));
+                            FP_MFMA_S(Sw[x], Kf[0], Q[x][0]);
+                        } else {
+                            FP_MFMA_SZ(Sw[x], Kf[0], Q[x][0]);
+                        }
                     } else {
                         FP_MFMA_S(Sw[x], Kf[kk], Q[x][kk]);
                     }
                 }
-            } else if (g < 16) {
+            } else if (g < NEX) {
                 if constexpr (PV) {
-                    const int i = g - 8, ks = i >> 2, db = (i >> 1) & 1, x = i & 1;
+                    const int i = g - NQK, ks = i / (2 * QB), db = (i / QB) & 1, x = i % QB;
                     FP_MFMA_O(O[x][db], Vf[ks][db], Pr[x][ks]);
                 }
             } else {
-                const int i = g - 16, ks = i >> 1, x = i & 1;
-                FP_MFMA_O(L[x], ONES, Pr[x][ks]);
+                const int i = g - NEX, ks = i / QB, x = i % QB;
+                FP_MFMA_L(L[x], ONES, Pr[x][ks]);
             }
-            if (g >= 16) continue;
+            if (g >= NEX) continue;
             // ---- vector work of this gap
-            // tracking pass: 16 v_max3 (8 per query block) in gaps 10..15: the last MFMA of block 0's chain is gap 6, of block
-            // 1's gap 7, and an MFMA result must not be read by a vector instruction within ~20 issue slots (no interlock, no
-            // padding inside asm)
-            constexpr int first_of[7] = {0, 3, 6, 9, 12, 14, 16};
-            int mj = 16, mj_end = 16;
+            // tracking pass: 8 QB v_max3 in gaps NQK+2 .. NEX-1: block x's score chain ends in gap NQK-QB+x, and an MFMA result
+            // must not be read by a vector instruction within ~20 issue slots (no interlock, no padding inside asm)
+            int mj = 0, mj_end = 0;
             if constexpr (MX) {
-                if constexpr (!PV) { if (g == 10) asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7"); }
-                if (g >= 10) { mj = first_of[g - 10]; mj_end = first_of[g - 9]; }
+                constexpr int G0 = NQK + 2, NGM = NEX - G0, NOP = 8 * QB;
+                if constexpr (!PV) { if (g == G0) asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7"); }
+                if (g >= G0) { mj = (g - G0) * NOP / NGM; mj_end = (g - G0 + 1) * NOP / NGM; }
             }
             auto max3_one = [&]() __attribute__((always_inline)) {
                 if (mj < mj_end) {
@@ -347,28 +362,33 @@ void flash_attn_d64_pipe_kernel(const bf16_t* __restrict__ q, const bf16_t* __re
                 }
             }
             max3_one();
-            if (g == 15) {
-                float t3;
-                if constexpr (MX) asm volatile("v_max3_f32 %0, %1, %2, %3" : "=v"(t3) : "v"(mx[0][0]), "v"(mx[0][1]), "v"(mx[1][0]));
-                if constexpr (EX) asm volatile("s_nop 1");
-                if constexpr (MX) asm volatile("v_max_f32 %0, %1, %2" : "=v"(mm) : "v"(t3), "v"(mx[1][1]));
+            if (g == NEX - 1) {
+                if constexpr (MX) {                  // mm = max over all chains (statements of one chain never adjacent)
+                    float t0, t1;
+                    asm volatile("v_max3_f32 %0, %1, %2, %3" : "=v"(t0) : "v"(mx[0][0]), "v"(mx[0][1]), "v"(mx[1][0]));
+                    if constexpr (QB == 3) asm volatile("v_max3_f32 %0, %1, %2, %3" : "=v"(t1) : "v"(mx[1][1]), "v"(mx[2][0]), "v"(mx[2][1]));
+                    else asm volatile("v_mov_b32 %0, %1" : "=v"(t1) : "v"(mx[1][1]));
+                    asm volatile("s_nop 1");
+                    asm volatile("v_max_f32 %0, %1, %2" : "=v"(mm) : "v"(t0), "v"(t1));
+                }
                 if constexpr (EX) {
+                    asm volatile("s_nop 1");
                     unsigned w;
-                    FP_CVT(w, pa[15], pb[15]);
-                    Pw[1][1][3] = w;
+                    FP_CVT(w, pa[NEX - 1], pb[NEX - 1]);
+                    Pw[QB - 1][1][3] = w;
                 }
             }
         }
     };
 
-    // ---- one pass over all keys. TRACK = false: m = row max of the first half tile, no v_max3 / decisions afterwards
+    // ---- one pass over all keys. TRACK = false: m = 0, no v_max3 / decisions
     auto run = [&](auto TRACK_) __attribute__((always_inline)) {
         using TRACK = std::bool_constant<decltype(TRACK_)::value>;
         using EXL = std::bool_constant<FP_LOOP_EX>;
         using T_ = std::true_type;
         using F_ = std::false_type;
 #pragma unroll
-        for (int x = 0; x < 2; ++x) {
+        for (int x = 0; x < QB; ++x) {
             mx[x][0] = 0.f; mx[x][1] = 0.f; m_run[x] = 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) { O[x][0][r] = 0.f; O[x][1][r] = 0.f; L[x][r] = 0.f; }
@@ -403,12 +423,12 @@ void flash_attn_d64_pipe_kernel(const bf16_t* __restrict__ q, const bf16_t* __re
         set_addr(ka, va, 0, 0);
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) rd_k(kk, ka[kk], 0);
-        // h = -2: S(0) = K(0) cQ^T and its row max; requests K(1)
-        step(ic<0>{}, F_{}, T_{}, T_{}, T_{}, F_{}, F_{}, T_{}, F_{}, ic<0>{}, ka, 1, va, 0, 0, 0);
-        rescale(S[0], P[0], true);
-        // h = -1: S(1) = K(1) cQ^T - m, P(0); requests K(2) (tile 1) and V(0)
+        // h = -2: S(0) = K(0) cQ^T (tracking pass: and its row max -> m); requests K(1)
+        step(ic<0>{}, TRACK{}, F_{}, T_{}, TRACK{}, F_{}, F_{}, T_{}, F_{}, ic<0>{}, ka, 1, va, 0, 0, 0);
+        if constexpr (TRACK::value) rescale(S[0], P[0], true);
+        // h = -1: S(1), P(0); requests K(2) (tile 1) and V(0)
         set_addr(kb2, vb2, 1, 0);
-        step(ic<1>{}, F_{}, T_{}, F_{}, TRACK{}, T_{}, F_{}, T_{}, T_{}, ic<0>{}, kb2, 0, va, 0, 0, 0);
+        step(ic<1>{}, TRACK{}, F_{}, T_{}, TRACK{}, T_{}, F_{}, T_{}, T_{}, ic<0>{}, kb2, 0, va, 0, 0, 0);
 
 #ifdef FP_STAMPS
         const unsigned long long st0 = __builtin_amdgcn_s_memtime(), sr0 = __builtin_amdgcn_s_memrealtime();
@@ -417,8 +437,8 @@ void flash_attn_d64_pipe_kernel(const bf16_t* __restrict__ q, const bf16_t* __re
         for (int T = 0; T < nt - 1; ++T) {
             set_addr(ka, va, (T + 1) & 3, T & 3);            // this iteration's second halves: K(T+1) rows 32.., V(T) rows 32..
             set_addr(kb2, vb2, (T + 2) & 3, (T + 1) & 3);    // the next iteration's first halves: K(T+2), V(T+1)
-            step(ic<0>{}, TRACK{}, T_{}, F_{}, TRACK{}, EXL{}, T_{}, T_{}, T_{}, ic<1>{}, ka, 1, va, 1, T + 3, (T + 2) & 3, va);
-            step(ic<1>{}, TRACK{}, T_{}, F_{}, TRACK{}, EXL{}, T_{}, T_{}, T_{}, ic<2>{}, kb2, 0, vb2, 0, 0, 0, va);
+            step(ic<0>{}, TRACK{}, TRACK{}, T_{}, TRACK{}, EXL{}, T_{}, T_{}, T_{}, ic<1>{}, ka, 1, va, 1, T + 3, (T + 2) & 3);
+            step(ic<1>{}, TRACK{}, TRACK{}, T_{}, TRACK{}, EXL{}, T_{}, T_{}, T_{}, ic<2>{}, kb2, 0, vb2, 0, 0, 0);
         }
 #ifdef FP_STAMPS
         if (tid == 0) {
@@ -429,19 +449,18 @@ void flash_attn_d64_pipe_kernel(const bf16_t* __restrict__ q, const bf16_t* __re
 #endif
         // the last tile's PV (its V fragments for the first half were requested by the loop's last step)
         set_addr(ka, va, 0, (nt - 1) & 3);
-        step(ic<0>{}, TRACK{}, F_{}, F_{}, F_{}, T_{}, T_{}, F_{}, T_{}, ic<0>{}, ka, 0, va, 1, 0, 0, va);
-        step(ic<1>{}, F_{}, F_{}, F_{}, F_{}, F_{}, T_{}, F_{}, F_{}, ic<0>{}, ka, 0, va, 0, 0, 0, va);
-        asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7" : "+a"(O[0][0]), "+a"(O[0][1]), "+a"(O[1][0]), "+a"(O[1][1]),
-                     "+a"(L[0]), "+a"(L[1]));
+        step(ic<0>{}, TRACK{}, TRACK{}, F_{}, F_{}, T_{}, T_{}, F_{}, T_{}, ic<0>{}, ka, 0, va, 1, 0, 0);
+        step(ic<1>{}, TRACK{}, F_{}, F_{}, F_{}, F_{}, T_{}, F_{}, F_{}, ic<0>{}, ka, 0, va, 0, 0, 0);
+        fp_settle<QB>(O, L);
     };
 
-    float l_tot[2];
+    float l_tot[QB];
     auto row_sums = [&]() __attribute__((always_inline)) {
         bool bad = false;
 #pragma unroll
-        for (int x = 0; x < 2; ++x) {
+        for (int x = 0; x < QB; ++x) {
             l_tot[x] = L[x][0];
-            bad |= !(l_tot[x] < 1.2676506e30f);          // 2^100; also true for NaN
+            bad |= !(l_tot[x] < 1.2676506e30f) || !(l_tot[x] > 7.8886091e-31f);     // outside [2^-100, 2^100), or NaN
         }
         return bad;
     };
@@ -458,7 +477,7 @@ void flash_attn_d64_pipe_kernel(const bf16_t* __restrict__ q, const bf16_t* __re
 
     // ---- epilogue: normalise, bf16, store
 #pragma unroll
-    for (int x = 0; x < 2; ++x) {
+    for (int x = 0; x < QB; ++x) {
         const float inv = 1.0f / l_tot[x];
         if (qrow[x] < Lq) {
             bf16_t* orow = ob + (size_t)qrow[x] * ldo;
@@ -490,13 +509,17 @@ extern "C" int dc_fp_debug_stamps(unsigned long long* out, int reset) {
 #endif
 
 // Mode of the long self-attention kernel (process-wide; tests and same-box A/B): bit 0 = run the tracking (online-softmax)
-// pass directly instead of as the fallback; thr = threshold of the tracking pass, in exp2 units, by which a score must
-// exceed the running max before the state is rescaled (P <= 2^thr otherwise). Initial values from DC_FLASH_TRACK /
+// pass directly instead of as the fallback; bit 1 = two query blocks per wave (256 rows per workgroup) for every shape (default:
+// three when Lq is a multiple of 384); thr = threshold of the tracking pass, in exp2 units, by which a score must exceed the
+// running max before the state is rescaled (P <= 2^thr otherwise). Initial values from DC_FLASH_TRACK / DC_FLASH_QB2 /
 // DC_FLASH_THR.
-static int g_fp_mode = [] { const char* t = getenv("DC_FLASH_TRACK"); return (t && t[0] == '1') ? 1 : 0; }();
+static int g_fp_mode = [] {
+    const char* t = getenv("DC_FLASH_TRACK"); const char* b = getenv("DC_FLASH_QB2");
+    return ((t && t[0] == '1') ? 1 : 0) | ((b && b[0] == '1') ? 2 : 0);
+}();
 static float g_fp_thr = [] { const char* e = getenv("DC_FLASH_THR"); return e ? (float)atof(e) : 8.0f; }();
 extern "C" int dc_flash_attn_set_mode(int mode, float thr) {
-    if (mode < 0 || mode > 1 || !(thr >= 0.f) || thr > 64.f) return DC_ERR_ARG;
+    if (mode < 0 || mode > 3 || !(thr >= 0.f) || thr > 64.f) return DC_ERR_ARG;
     g_fp_mode = mode; g_fp_thr = thr;
     return 0;
 }
@@ -508,19 +531,22 @@ int dc_flash_pipe_launch(const bf16_t* q, const bf16_t* k, const bf16_t* v, bf16
                          hipStream_t stream) {
     const float thr = g_fp_thr;
     const int force_track = g_fp_mode & 1;
-    static bool configured[16] = {};
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return DC_ERR_ARG;
-    if (dev < 0 || dev >= 16 || !configured[dev]) {
-        hipError_t e = hipFuncSetAttribute((const void*)flash_attn_d64_pipe_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, FP_LDS);
-        if (e != hipSuccess) return (int)e;
-        if (dev >= 0 && dev < 16) configured[dev] = true;
-    }
-    const int q_tiles = (Lq + FP_ROWS - 1) / FP_ROWS;
+    static DcLdsOnce once2, once3;
+    if (const int e = once2.ensure((const void*)flash_attn_d64_pipe_kernel<2>, FP_LDS)) return e;
+    if (const int e = once3.ensure((const void*)flash_attn_d64_pipe_kernel<3>, FP_LDS)) return e;
+    const bool qb3 = !(g_fp_mode & 2) && Lq % 384 == 0;
+    const int rows = qb3 ? 384 : 256;
+    const int q_tiles = (Lq + rows - 1) / rows;
     const long long nwg = (long long)q_tiles * heads * batch;
     if (nwg > 0x7fffffffLL) return DC_ERR_SHAPE;
-    hipLaunchKernelGGL(flash_attn_d64_pipe_kernel, dim3((unsigned)nwg), dim3(256), FP_LDS, stream, q, k, v, o, ldq, ldk, ldv, ldo,
-                       heads, Lq, Lk, q_bstride, kv_bstride, c, q_tiles, thr, force_track);
+    // the byte offsets of the K / V buffer loads are 32-bit
+    if ((long long)Lk * ldk * 2 >= 0x7fffffffLL || (long long)Lk * ldv * 2 >= 0x7fffffffLL) return DC_ERR_SHAPE;
+    if (qb3)
+        hipLaunchKernelGGL(flash_attn_d64_pipe_kernel<3>, dim3((unsigned)nwg), dim3(256), FP_LDS, stream, q, k, v, o, ldq, ldk, ldv,
+                           ldo, heads, Lq, Lk, q_bstride, kv_bstride, c, q_tiles, thr, force_track);
+    else
+        hipLaunchKernelGGL(flash_attn_d64_pipe_kernel<2>, dim3((unsigned)nwg), dim3(256), FP_LDS, stream, q, k, v, o, ldq, ldk, ldv,
+                           ldo, heads, Lq, Lk, q_bstride, kv_bstride, c, q_tiles, thr, force_track);
     DC_CHECK_LAUNCH();
     return 0;
 }

@@ -849,13 +849,8 @@ int launch_persist_epi_st(const DcGemmParams& p, hipStream_t stream, int grid) {
     constexpr int ST = ST_FORCE ? ST_FORCE : ((BN <= 128) ? 3 : 2);
     constexpr size_t lds = (size_t)ST * (GBM * GBK * 2 + BN * GBK * 2) + 8 * 2048;
     static_assert(lds <= 163840, "LDS budget");
-    static bool configured = false;
-    if (!configured) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_persist_kernel<BN, GEGLU, ST, EPI, MODE>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return (int)e;
-        configured = true;
-    }
+    static DcLdsOnce lds_once;
+    if (const int e = lds_once.ensure(reinterpret_cast<const void*>(&gemm_persist_kernel<BN, GEGLU, ST, EPI, MODE>), (int)lds)) return e;
     dc_note_variant(GEGLU ? (BN == 256 ? "gemm_persist_kernel<256,geglu>" : "gemm_persist_kernel<128,geglu>")
                     : MODE == 1 ? "gemm_persist_kernel<320,conv>" : MODE == 2 ? "gemm_persist_kernel<320,tconv>"
                     : BN == 320 ? (EPI == 1 || EPI == 3 ? "gemm_persist_kernel<320,residual>" : "gemm_persist_kernel<320>")
@@ -905,13 +900,8 @@ int launch_glds(const DcGemmParams& p, hipStream_t stream) {
     const int tiles_n = (n_out + BNOUT - 1) / BNOUT;
     const int tiles_m = (p.M + GBM - 1) / GBM;
     constexpr size_t lds = (size_t)GSTAGES * (GBM * GBK * 2 + BN * GBK * 2);
-    static bool configured = false;
-    if (!configured) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_conv_glds_kernel<BN, GEGLU, MODE, GSTAGES>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return (int)e;
-        configured = true;
-    }
+    static DcLdsOnce lds_once;
+    if (const int e = lds_once.ensure(reinterpret_cast<const void*>(&gemm_conv_glds_kernel<BN, GEGLU, MODE, GSTAGES>), (int)lds)) return e;
     GemmSplit sp;
     sp.partial = nullptr; sp.splits = 1; sp.tile_begin = 0; sp.tile_count = tiles_m * tiles_n;
     dc_note_variant(GEGLU ? "gemm_conv_glds_kernel<geglu>"
@@ -929,13 +919,8 @@ template <int MODE>
 int launch_glds320_split(const DcGemmParams& p, hipStream_t stream, int ntiles, int full, int splits) {
     constexpr int BN = 320, GSTAGES = 2;
     constexpr size_t lds = (size_t)GSTAGES * (GBM * GBK * 2 + BN * GBK * 2);
-    static bool configured = false;
-    if (!configured) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_conv_glds_kernel<BN, false, MODE, GSTAGES>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return (int)e;
-        configured = true;
-    }
+    static DcLdsOnce lds_once;
+    if (const int e = lds_once.ensure(reinterpret_cast<const void*>(&gemm_conv_glds_kernel<BN, false, MODE, GSTAGES>), (int)lds)) return e;
     dc_note_variant(MODE == 0 ? "gemm_conv_glds_kernel<320>+splitk" : MODE == 2 ? "gemm_conv_glds_kernel<320,tconv>+splitk" : "gemm_conv_glds_kernel<320,conv>+splitk");
     GemmSplit sp;
     if (full > 0) {

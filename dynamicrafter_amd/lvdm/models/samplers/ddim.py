@@ -37,6 +37,10 @@ class FusedRun:
         self.S = sampler._exec_timesteps.shape[0]
         self.nb = len(branches)
         self.prep = m.prepare_branches(tuple(img.shape), branches, fs=fs)
+        for name, t in (("noises", noises), ("q_noises", None if (mask is None or clean_cond) else q_noises)):
+            if t is not None and t.numel() < self.S * img.numel():
+                raise ValueError(f"{name}: the step kernels read step index * {img.numel()} + i for {self.S} steps; "
+                                 f"got {t.numel()} elements")
         self.noises = noises
         self.pred_x0 = torch.empty_like(img)
         self.ws = torch.empty(16 * b * 256, dtype=torch.float32, device=dev)
@@ -204,16 +208,31 @@ class DDIMSampler(object):
         if cfg_img is None:
             cfg_img = unconditional_guidance_scale
         eta_on = bool((self._tables["sigma_t"] != 0).any().item())
-        if noises is None and eta_on:
-            # drawn up front so a captured graph can index them by the device step counter (same stream of
-            # torch.randn draws as the reference's per-step noise_like calls)
-            noises = torch.stack([torch.randn(shape, device=dev) for _ in range(S)])
+        q_noises = kwargs.pop("q_noises", None)
+        draw_q = mask is not None and not clean_cond and q_noises is None
+        if (noises is None and eta_on) or draw_q:
+            # drawn up front so a captured graph can index them by the device step counter - in the order of the reference's
+            # per-step draws: with a mask, q_sample's randn_like of step i comes before that step's noise_like
+            # (ddim.py:174-180, then p_sample_ddim :270)
+            qs, ns = [], []
+            for _ in range(S):
+                if draw_q:
+                    qs.append(torch.randn(shape, device=dev))
+                if noises is None and eta_on:
+                    ns.append(torch.randn(shape, device=dev))
+            if qs:
+                q_noises = torch.stack(qs)
+            if ns:
+                noises = torch.stack(ns)
         if noises is not None:
             noises = noises.to(device=dev, dtype=torch.float32).contiguous()
+        if noises is not None and noises.numel() < S * img.numel():
+            raise ValueError(f"noises: {S} steps x {img.numel()} elements needed, got {noises.numel()}")
+        if mask is not None and not clean_cond and q_noises.numel() < S * img.numel():
+            raise ValueError(f"q_noises: {S} steps x {img.numel()} elements needed, got {q_noises.numel()}")
         fast = hasattr(m, "apply_model_rows") and all(isinstance(c, dict) for c in branches)
         intermediates = {"x_inter": [img.clone()], "pred_x0": [img.clone()]}
 
-        q_noises = kwargs.pop("q_noises", None)
         if fast:
             run = FusedRun(self, img, branches, fs=fs, noises=noises, cfg_scale=unconditional_guidance_scale,
                            cfg_img=cfg_img, guidance_rescale=guidance_rescale, temperature=temperature, mask=mask,
@@ -222,13 +241,15 @@ class DDIMSampler(object):
                 run.capture()
             for i in range(S):
                 run.step()
-                if not use_graph:
-                    index = S - i - 1
-                    if callback: callback(i)
-                    if img_callback: img_callback(run.pred_x0, i)
-                    if index % log_every_t == 0 or index == S - 1:
-                        intermediates["x_inter"].append(img.clone())
-                        intermediates["pred_x0"].append(run.pred_x0.clone())
+                index = S - i - 1
+                log_now = index % log_every_t == 0 or index == S - 1
+                if use_graph and (callback or img_callback or log_now):
+                    run.sync()                 # the graph runs on its own stream: the step must have finished before the
+                if callback: callback(i)       # callbacks / snapshots read its results (ddim.py:196-201)
+                if img_callback: img_callback(run.pred_x0, i)
+                if log_now:
+                    intermediates["x_inter"].append(img.clone())
+                    intermediates["pred_x0"].append(run.pred_x0.clone())
             run.sync()
             self._last_run = run
             return img, intermediates
@@ -240,9 +261,7 @@ class DDIMSampler(object):
             if mask is not None:
                 assert x0 is not None
                 full = lambda t: t.to(device=dev, dtype=torch.float32).expand_as(img).contiguous()
-                qn = None
-                if not clean_cond:
-                    qn = torch.randn_like(img) if q_noises is None else q_noises[i].to(dev, torch.float32).contiguous()
+                qn = None if clean_cond else q_noises[i].to(dev, torch.float32).contiguous()
                 img = ops.mask_blend(img.contiguous().clone(), full(x0), full(mask), qn, self._tables, index=i,
                                      clean=clean_cond)
             img, pred_x0 = self.p_sample_ddim(img, cond, ts, index=index, temperature=temperature,

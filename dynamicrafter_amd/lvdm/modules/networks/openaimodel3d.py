@@ -300,6 +300,7 @@ class UNetModel(nn.Module):
                     d["ip_scale"] = float(torch.tanh(self._p(a + ".alpha").detach().float()).item() + 1.0)
             else:
                 d["attn2"] = attn_self(p + ".attn2")
+            d["key"] = p                       # stable name of the block (keys the hoisted context K/V of a sampler run)
             return d
 
         def with_projp(d, p):
@@ -358,6 +359,8 @@ class UNetModel(nn.Module):
         P["out_gn"] = (f32("out.0.weight"), f32("out.0.bias"))
         P["out_conv"] = PackedWeight.conv3x3(self._p("out.2.weight"), self._p("out.2.bias"), device, n_align=4)
         P["device"] = device
+        self._pack_gen = getattr(self, "_pack_gen", 0) + 1
+        P["gen"] = self._pack_gen              # a hoisted context K/V is only valid for the table it was projected with
         return P
 
     def packed(self, device):
@@ -484,15 +487,17 @@ class UNetModel(nn.Module):
         return ops.gemm(ctx, B_["kv_ctx"], self._arena.get(tag, ctx.shape[0], B_["kv_ctx"].N, device=ctx.device))
 
     def precompute_context_kv(self, ctx_rows):
-        """All cross-attention K/V projections of a run's (step-invariant) context rows -> {id(block weights): kv}."""
+        """All cross-attention K/V projections of a run's (step-invariant) context rows -> {block name: kv} + the generation
+        of the packed weight table they were computed with (a repack in between - load_state_dict - invalidates them: the
+        forward then projects the context itself, as the reference does every step)."""
         Wt = self.packed(ctx_rows.device)
         down_path, middle, up_path = self._layout
-        out = {}
+        out = {"__gen__": Wt["gen"]}
         for name, blks, Ws in (("in", down_path, Wt["in"]), ("mid", [middle], [Wt["mid"]]), ("out", up_path, Wt["out"])):
             for i, (blk, Wb) in enumerate(zip(blks, Ws)):
                 for j, ((kind, a), W) in enumerate(zip(blk, Wb)):
                     if kind == "spatial":
-                        out[id(W["blk"])] = self._context_kv(W["blk"], ctx_rows, f"kvctx.{name}{i}.{j}")
+                        out[W["blk"]["key"]] = self._context_kv(W["blk"], ctx_rows, f"kvctx.{name}{i}.{j}")
         return out
 
     def _spatial_post(self, W, x, h, g, heads, out_tag, out=None):
@@ -501,7 +506,7 @@ class UNetModel(nn.Module):
         M, dev, Cc = x.shape[0], x.device, x.shape[1]
         B_ = W["blk"]
         q = self._ln_linear(h, B_["norm2"], B_["q2"], A.get("q2", M, Cc, device=dev))
-        kv = None if g.get("ctx_kv") is None else g["ctx_kv"].get(id(B_))
+        kv = None if g.get("ctx_kv") is None else g["ctx_kv"].get(B_["key"])
         if kv is None:
             kv = self._context_kv(B_, g["ctx"], "kvctx")       # rows [F * Lc, 4C], Lc = n_text + L_img
         att = A.get("att", M, Cc, device=dev)
@@ -593,6 +598,8 @@ class UNetModel(nn.Module):
             ops.timestep_embedding(fs_table, femb, mc)
             ops.gemv_small(femb, Wt["fps0"], hid, act_out=1)
             ops.gemv_small(hid, Wt["fps2"], emb, accumulate=True)
+        if ctx_kv is not None and ctx_kv.get("__gen__") != Wt["gen"]:
+            ctx_kv = None                      # projected with weights that have been repacked since: project here
         g = dict(B=B, T=T, F=B * T, H=H, W=W, HW=H * W, emb=emb, ctx=ctx_rows, Lc=Lc, n_text=n_text, ctx_kv=ctx_kv)
         down_path, middle, up_path = self._layout
         n_up = len(up_path)

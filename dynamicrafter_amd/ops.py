@@ -680,8 +680,9 @@ def mask_blend(img, x0, mask, qnoise, tables, *, index=0, step_index=None, clean
     if img.dtype != torch.float32 or not img.is_contiguous():
         raise ValueError("mask_blend: latent must be contiguous fp32")
     if not clean:
-        need = n if step_index is None else n            # at least one step's worth; the sampler sizes it [S, ...]
-        _need(qnoise, need, "qnoise")
+        # with a device step counter the kernel reads qnoise[step * noise_step_stride + i], step < the number of table rows
+        steps = int(tables["sqrt_acp_t"].numel()) if step_index is not None else 1
+        _need(qnoise, (steps - 1) * noise_step_stride + n if step_index is not None else n, "qnoise")
     check(_hip.lib().dc_mask_blend(_ptr(img), _ptr(x0), _ptr(mask), _ptr(None if clean else qnoise),
                                    _ptr(tables.get("sqrt_acp_t")), _ptr(tables.get("sqrt_1macp_t")), _ptr(step_index), index,
                                    n, noise_step_stride, 1 if clean else 0, stream_ptr()), "dc_mask_blend")

@@ -36,6 +36,8 @@ CFG_DIR = os.path.join(HERE, "..", "dynamicrafter_amd", "configs")
 
 UNET_TOL, UNET_COS = 3e-2, 0.9997
 STEP_TOL = 2.3e-2
+# classifier-free guidance at scale 7.5 amplifies the branch errors (g = 7.5 e_c - 6.5 e_u); provisional bounds until measured
+GUIDED_TOL, GUIDED_STEP_TOL = 0.5, 0.5
 AE_MOM_TOL, AE_Z_TOL, AE_DEC_TOL = 3e-2, 1e-2, 2.7e-2
 
 
@@ -144,14 +146,26 @@ def _run_case(model, ocfg, sd, *, x, cc, ctx, uc_ctx, fs, disc, eta, gr, tag, go
         assert rg < UNET_TOL
     assert torch.isfinite(e).all()
     assert max(r) < UNET_TOL and min(c) > UNET_COS
-    # ---- one fused DDIM update on the same state (eager launches; the graph replays exactly these)
-    x_prev = None
-    if golden_t is None:
-        run.step()
-        run.sync()
-        torch.cuda.synchronize()
-        x_prev = run.img.detach().float().cpu()
-    return dict(e=e, ref=ref, x_prev=x_prev, noises=noises, t_step=t_step, S=S)
+    # ---- one fused DDIM update on the same state (eager launches; the graph replays exactly these). With a fixture timestep
+    # the network ran at that t while the update uses step 0's coefficients - the same function on both sides.
+    run.step()
+    run.sync()
+    torch.cuda.synchronize()
+    x_prev = run.img.detach().float().cpu()
+    guided = None
+    if oracle_both:
+        # classifier-free guidance amplifies the (uncorrelated) errors of the two branches: g = e_u + 7.5 (e_c - e_u) =
+        # 7.5 e_c - 6.5 e_u. Measured here on the guided model output and on x_prev of a full HIP step against the full
+        # oracle step (both branches from both sides).
+        g_hip = e[1] + 7.5 * (e[0] - e[1])
+        g_ref = ref[1] + 7.5 * (ref[0] - ref[1])
+        xp_ref = _oracle_step(tag.split("-")[0], [ref[0], ref[1]], x, noises[0], S, disc, eta, gr, S - 1)
+        guided = dict(g=rel_l2(g_hip, g_ref), x_prev=rel_l2(x_prev, xp_ref),
+                      diff=rel_l2(e[0] - e[1], ref[0] - ref[1]), ratio=float((ref[0] - ref[1]).norm() / ref[0].norm()))
+        print(f"[fullsize {tag}] guided output g = e_u + 7.5 (e_c - e_u): HIP vs oracle rel-L2 {guided['g']:.3e} "
+              f"(e_c - e_u alone: {guided['diff']:.3e}; |e_c - e_u| / |e_c| = {guided['ratio']:.3f}); "
+              f"x_prev of the full HIP step vs the full oracle step: rel-L2 {guided['x_prev']:.3e}")
+    return dict(e=e, ref=ref, x_prev=x_prev, noises=noises, t_step=t_step, S=S, guided=guided)
 
 
 def _oracle_step(tag, ref, x, noise, S, disc, eta, gr, index):
@@ -210,6 +224,7 @@ def test_unet_40x64_config2_and_5(model_v):
     out = _run_case(model, ocfg, sd, x=x, cc=cc, ctx=ctx, uc_ctx=uc_ctx, fs=fs, disc="uniform_trailing", eta=1.0,
                     gr=0.7, tag="512-interp", golden_y=torch.from_numpy(g["y"])[0], golden_t=int(g["timesteps"][0]))
     assert out["t_step"] == int(g["timesteps"][0])
+    assert out["guided"]["g"] < GUIDED_TOL and out["guided"]["x_prev"] < GUIDED_STEP_TOL
 
 
 def test_unet_32x32_config1():
@@ -224,6 +239,7 @@ def test_unet_32x32_config1():
         out = _run_case(model, ocfg, sd, x=x, cc=cc, ctx=ctx, uc_ctx=uc_ctx, fs=fs, disc="uniform", eta=0.0, gr=0.0,
                         tag="256", golden_y=torch.from_numpy(g["y"])[0], golden_t=int(g["timesteps"][0]))
         assert out["t_step"] == int(g["timesteps"][0])
+        assert out["guided"]["g"] < GUIDED_TOL and out["guided"]["x_prev"] < GUIDED_STEP_TOL
     finally:
         del model, sd
         gc.collect()

@@ -462,6 +462,48 @@ def test_sampler_mask_decode_stochastic_encode_vs_reference():
     assert maxrel(s.stochastic_encode(x0, T(g["enc/t_orig"]), use_original_steps=True, noise=n), g["enc/orig"]) < 1e-6
 
 
+def test_sampler_mask_default_noise_draw_order_and_graph_bookkeeping():
+    """With a mask and no injected noises the reference draws, per step, q_sample's randn_like and then the step's noise
+    (ddim.py:174-180, :270): the fused path pre-draws both in that interleaved order, so the same seed gives the same sample
+    as drawing them step by step and injecting them. Under use_graph=True callback / img_callback / intermediates behave as
+    in the eager loop (the step has finished when they run)."""
+    from dynamicrafter_amd.lvdm.models.samplers.ddim import DDIMSampler
+    g = load("sampler_extras")
+    model = _tiny_lvd("inference_512_v1.0.yaml")
+    cond = {"c_crossattn": [T(g["ctx"])], "c_concat": [T(g["c_concat"])]}
+    uc = {"c_crossattn": [T(g["uc_ctx"])], "c_concat": [T(g["c_concat"])]}
+    x_T, x0, mask = T(g["x_T"]), T(g["x0"]), T(g["mask"])
+    S = 6
+    kw = dict(S=S, batch_size=1, shape=tuple(x_T.shape[1:]), conditioning=cond, verbose=False, mask=mask, x0=x0,
+              unconditional_guidance_scale=7.5, unconditional_conditioning=uc, eta=1.0, x_T=x_T, fs=T(g["fs"]),
+              timestep_spacing="uniform_trailing", guidance_rescale=0.7)
+    torch.manual_seed(4321)
+    a, _ = DDIMSampler(model).sample(**kw)
+    torch.manual_seed(4321)                                   # the reference's order, drawn by hand and injected
+    qs, ns = [], []
+    for _ in range(S):
+        qs.append(torch.randn(x_T.shape, device=DEV)); ns.append(torch.randn(x_T.shape, device=DEV))
+    b, _ = DDIMSampler(model).sample(noises=torch.stack(ns), q_noises=torch.stack(qs), **kw)
+    assert torch.equal(a, b)
+    with pytest.raises(ValueError):                           # a noise buffer shorter than S steps is refused up front
+        DDIMSampler(model).sample(noises=torch.stack(ns[:3]), q_noises=torch.stack(qs), **kw)
+    # bookkeeping under the captured graph == eager
+    rec = {}
+    for use_graph in (False, True):
+        calls, snaps = [], []
+        torch.manual_seed(99)
+        out, inter = DDIMSampler(model).sample(callback=lambda i: calls.append(i),
+                                               img_callback=lambda p, i: snaps.append((i, p.clone())), log_every_t=2,
+                                               use_graph=use_graph, **kw)
+        rec[use_graph] = (out, inter, calls, snaps)
+    (o0, i0, c0, s0), (o1, i1, c1, s1) = rec[False], rec[True]
+    assert torch.equal(o0, o1) and c0 == c1 == list(range(S)) and len(s0) == len(s1) == S
+    assert all(torch.equal(p0, p1) for (_, p0), (_, p1) in zip(s0, s1))
+    assert len(i0["x_inter"]) == len(i1["x_inter"]) > 2
+    assert all(torch.equal(x, y) for x, y in zip(i0["x_inter"], i1["x_inter"]))
+    assert all(torch.equal(x, y) for x, y in zip(i0["pred_x0"], i1["pred_x0"]))
+
+
 def test_frames_to_uint8_and_writers(tmp_path):
     """Output side (inference.py:115-162): clamp / (v+1)/2 / x255 / uint8 truncation / side-by-side grid in one kernel,
     bit-exact against the reference's torch expression; APNG container round trip."""
@@ -550,6 +592,28 @@ def test_bench_two_ranks_share_one_gpu_gloo():
     assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["config"]["outputs_finite"]
     assert len(out["config"]["per_rank"]) == 2 and "scatter_conditioning" in out["config"]["conditioning"]
     assert abs(out["value"] - 2 * 16 / out["config"]["clip_seconds"]) < 1e-3 * out["value"]
+    assert out["n_ranks_seen"] == 2 and out["backend"] == "gloo"
+
+
+def test_bench_gpus_2_launches_itself():
+    """`python bench.py --gpus 2` run DIRECTLY (no launcher, WORLD_SIZE unset), the way the driver runs `--gpus 1`: bench.py
+    must start torch.distributed.run itself as a child process, relay rank 0's one JSON line and the return code. Rehearsed on
+    this box's single GPU with gloo collectives (DC_BENCH_BACKEND / DC_BENCH_SHARE_GPU)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.join(os.path.dirname(G), "..")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(DC_BENCH_BACKEND="gloo", DC_BENCH_SHARE_GPU="1")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--res", "256", "--no-ae", "--no-trace", "--no-cpu-baseline"], capture_output=True, text=True,
+                       env=env, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(line) == 1
+    out = json.loads(line[0])
+    assert out["n_gpus"] == 2 and out["n_ranks_seen"] == 2 and out["backend"] == "gloo"
+    assert out["config"]["outputs_finite"] and len(out["config"]["per_rank"]) == 2
 
 
 def test_ae_frames_per_call_keeps_per_frame_results():

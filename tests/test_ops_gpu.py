@@ -199,9 +199,10 @@ def test_flash_attn_fused_qkv_and_spike(ops):
     assert rel_l2(o, ref) < 6e-3
 
 
-# modes of the long self-attention kernel (dc_flash_attn_set_mode): (mode, thr) - default = the shift of the first half tile
-# kept for the whole pass; bit 0 = the running-max (tracking) pass run directly, with thr = 0 (rescale on every growth) and 8
-FLASH_MODES = [(0, 8.0), (1, 0.0), (1, 8.0)]
+# modes of the long self-attention kernel (dc_flash_attn_set_mode): (mode, thr) - default = no running max in the main pass (shift
+# 0, out-of-range row sums fall back to the tracking pass), three query blocks per wave when Lq % 384 == 0; bit 0 = the
+# running-max (tracking) pass run directly, with thr = 0 (rescale on every growth) and 8; bit 1 = two query blocks per wave
+FLASH_MODES = [(0, 8.0), (1, 0.0), (1, 8.0), (2, 8.0), (3, 0.0)]
 
 
 @pytest.fixture
@@ -215,7 +216,7 @@ def flash_mode(request):
 
 @pytest.mark.parametrize("flash_mode", FLASH_MODES, indirect=True)
 @pytest.mark.parametrize("B,heads,Lq,Lk", [(2, 2, 1024, 1024), (1, 3, 768, 256), (1, 1, 1000, 512), (1, 2, 512, 2304),
-                                           (1, 1, 530, 128 + 64)])
+                                           (2, 1, 1152, 1152), (1, 1, 530, 128 + 64)])
 def test_flash_attn_long_self(ops, flash_mode, B, heads, Lq, Lk):
     """Shapes that take the one-wave-per-SIMD software-pipelined kernel (flash_pipe.hip: Lq >= 512, Lk >= 256, Lk % 64 == 0)
     and, last case, its boundary (Lk = 192 stays on the two-waves kernel). Ragged Lq exercises the clamped tail rows."""
@@ -231,13 +232,14 @@ def test_flash_attn_long_self(ops, flash_mode, B, heads, Lq, Lk):
 @pytest.mark.parametrize("flash_mode", FLASH_MODES, indirect=True)
 @pytest.mark.parametrize("spikes", [(5,), (40,), (70,), (100,), (130, 131), (511,), (480,), (449, 20), (200, 300, 400, 500),
                                     tuple(range(0, 512, 37))])
-def test_flash_attn_long_self_running_max_jumps(ops, flash_mode, spikes):
+@pytest.mark.parametrize("L", [512, 768])
+def test_flash_attn_long_self_running_max_jumps(ops, flash_mode, spikes, L):
     """Keys with 6-14x the norm at chosen positions (first / second half tile, tile seams, the last half tiles, many at
     once; growing sizes so that each raises the maximum again). The default pass keeps the shift of the first 32 keys (its P
     then reach 2^40 and more: same relative precision); the tracking pass decides one half tile late whether a row's running
     max grew and rescales O, the row sums and the already packed P of the pending half tile - the spikes force that path at
-    every stage of its pipeline."""
-    B, heads, L = 1, 2, 512
+    every stage of its pipeline. L = 768 takes the three-blocks-per-wave kernel."""
+    B, heads = 1, 2
     Cc = heads * 64
     qkv = rnd(B * L, 3 * Cc, seed=21)
     for n, pos in enumerate(spikes):
@@ -252,13 +254,14 @@ def test_flash_attn_long_self_running_max_jumps(ops, flash_mode, spikes):
     assert rel_l2(o, ref) < 6e-3
 
 
-@pytest.mark.parametrize("pos", [33, 100, 300, 511])
-def test_flash_attn_long_self_fallback_to_tracking_pass(ops, pos):
-    """A key far outside the range of the first 32: its scores exceed the first-half-tile maximum by > 2^100 in exp2 units
-    for most rows, the default pass's row sums overflow, and the workgroup must repeat its block with the running-max pass
-    (scores ~ +-150 nats: softmax is a one-hot on the spiked key for rows with a positive score, and the plain softmax
-    elsewhere). A second launch with ordinary data follows: the fallback leaves no state behind."""
-    B, heads, L = 1, 2, 512
+@pytest.mark.parametrize("L", [512, 768])
+@pytest.mark.parametrize("pos", [3, 33, 100, 300, 511])
+def test_flash_attn_long_self_fallback_to_tracking_pass(ops, pos, L):
+    """A key whose scores reach +-600 in exp2 units: the default pass (no running max) overflows its row sums for most rows
+    and the workgroup must repeat its block with the running-max pass (softmax is a one-hot on the spiked key for rows
+    with a positive score, and the plain softmax elsewhere). A second launch with ordinary data follows: the fallback
+    leaves no state behind."""
+    B, heads = 1, 2
     Cc = heads * 64
     qkv = rnd(B * L, 3 * Cc, seed=41)
     qkv[pos, Cc:2 * Cc] *= 150.0
@@ -277,6 +280,23 @@ def test_flash_attn_long_self_fallback_to_tracking_pass(ops, pos):
     f = qkv2.float().cpu().reshape(B, L, 3 * Cc)
     ref = _attn_ref(f[..., :Cc], f[..., Cc:2 * Cc], f[..., 2 * Cc:], heads, 0.125).reshape(-1, Cc)
     assert rel_l2(o, ref) < 6e-3
+
+
+def test_flash_attn_long_self_all_scores_far_below_zero(ops):
+    """Every score of some rows below -100 in exp2 units (q and all keys anti-aligned and large): the default pass's row sums
+    underflow there and the fallback must produce the ordinary softmax."""
+    B, heads, L = 1, 1, 768
+    g = torch.Generator().manual_seed(51)
+    u = torch.randn(64, generator=g); u = u / u.norm()
+    q = rnd(L, 64, seed=52); k = rnd(L, 64, seed=53); v = rnd(L, 64, seed=54)
+    k = k + 40.0 * u                       # every key has a large component along u
+    q[100:140] = q[100:140] - 30.0 * u     # these queries point the other way: scores ~ -1200 / 8 = -150 nats
+    q, k, v = bf(q), bf(k), bf(v)
+    o = torch.zeros(L, 64, dtype=torch.bfloat16, device=DEV)
+    ops.flash_attn(q.to(DEV), k.to(DEV), v.to(DEV), o, batch=B, heads=heads, Lq=L, Lk=L, scale=0.125)
+    ref = _attn_ref(q.float()[None], k.float()[None], v.float()[None], heads, 0.125).reshape(-1, 64)
+    assert torch.isfinite(o.float()).all()
+    assert rel_l2(o, ref) < 1.6e-2
 
 
 def test_flash_attn_long_self_strided_batches(ops):

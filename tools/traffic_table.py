@@ -18,16 +18,21 @@ import sys
 from collections import defaultdict
 
 STEPS = 4
-SETUP = re.compile(r"elementwise_kernel|vectorized|distribution|fill|copy_|Memcpy|index|cat|arange|philox|normal|random", re.I)
+# not part of a denoising step: torch's own kernels (model build, weight repack, randn: at::native::*), runtime copies
+SETUP = re.compile(r"^at::|^at_|^__amd_rocclr|elementwise_kernel|vectorized|distribution|fill|copy_|copyBuffer|Memcpy|index|"
+                   r"cat|arange|philox|normal|random", re.I)
 
 
 def family(name):
+    """Kernel family = qualified name (namespaces kept: `at::native::...` must not collapse into `at`) + template arguments."""
     n = re.sub(r"^void\s+", "", name)
     n = re.sub(r"\(anonymous namespace\)::", "", n)
-    m = re.match(r"([A-Za-z0-9_]+)(<[^(]*>)?", n)
+    m = re.match(r"((?:[A-Za-z0-9_]+::)*[A-Za-z0-9_]+)(<[^(]*>)?", n)
     base = m.group(1) if m else n
     targs = (m.group(2) or "") if m else ""
     targs = targs.replace(" ", "")
+    if base.startswith("at::"):
+        return base                      # one family per torch kernel name; their template arguments are noise here
     return base + targs
 
 
@@ -52,7 +57,7 @@ def main():
         rd = 2.0 * fe.get(k, [0, 0])[0] * 1024
         wb = wr.get(k, [0, 0])[0] * 1024
         n = max(fe.get(k, [0, 0])[1], wr.get(k, [0, 0])[1])
-        rows.append(dict(kernel=k, dispatches=n, setup=bool(SETUP.search(k)) and not k.startswith(("gemm", "flash", "gn_", "layernorm")),
+        rows.append(dict(kernel=k, dispatches=n, setup=bool(SETUP.search(k)) and not k.startswith(("gemm", "flash", "gn_", "layernorm", "dc_", "ff_", "norm_", "ln_")),
                          read_gb_per_step=rd / STEPS / 1e9, write_gb_per_step=wb / STEPS / 1e9))
     rows.sort(key=lambda r: -(r["read_gb_per_step"] + r["write_gb_per_step"]))
     step_rows = [r for r in rows if not r["setup"]]
