@@ -62,6 +62,7 @@ SIGNATURES = {
     "dc_groupnorm_stats": (_I, [_P, _I, _I, _I, _I, _I, _F, _P, _P, _P]),
     "dc_gn_linear": (_I, [_P, _I, _I, _P, _P, _P, _I, _I, _P, _P, _P, _I, _I, _I, _P]),
     "dc_flash_attn_set_mode": (_I, [_I, _F]),
+    "dc_linear_residual": (_I, [_P, _I, _I, _P, _P, _P, _I, _P, _I, _I, _I, _P]),
     "dc_cross_attn_dual_d64": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _L, _L, _F, _F, _P]),
     "dc_temporal_attn_d64": (_I, [_P, _I, _P, _I, _I, _I, _I, _I, _F, _P]),
     "dc_gemv_small": (_I, [_P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
@@ -113,6 +114,10 @@ def lib():
                 raise RuntimeError(
                     f"{LIB_PATH} not found: build it with dynamicrafter_amd/csrc/build.sh "
                     "(or __graft_entry__.build()); the HIP extension is mandatory, there is no fallback")
+            # PyTorch-ROCm bundles its own HIP runtime (torch/lib/libamdhip64.so): it must be the one in the process BEFORE this
+            # library pulls in /opt/rocm's copy, or the kernels launch on a second runtime that has no device context
+            # (hipErrorNoDevice at the first launch - seen when build() loaded the library ahead of `import torch`)
+            import torch  # noqa: F401
             l = C.CDLL(LIB_PATH)
             for name, (res, args) in SIGNATURES.items():
                 fn = getattr(l, name)  # AttributeError if the symbol is missing

@@ -637,7 +637,9 @@ void ff_geglu_fused320_kernel(const FfParams p) {
 // slots would leave the second round almost empty).
 constexpr int LCH = 32;                        // output channels per chunk
 constexpr int LW_STAGE = LCH * FD * 2;         // 20 KB: 5 K tiles of [32 rows][128 B]
-constexpr int ll_lds(int kh) { return 2 * LW_STAGE + 4 * 2048 + 2 * FD * kh * 4; }      // ring + epilogue patches + gamma / beta
+constexpr int LL_BIAS = 640;                   // bias entries kept in LDS (N <= 640: every bias-carrying use in the UNet)
+// ring + epilogue patches + gamma / beta + bias (K = 320: 54272 B, three workgroups per CU still fit the 160 KB)
+constexpr int ll_lds(int kh) { return 2 * LW_STAGE + 4 * 2048 + 2 * FD * kh * 4 + LL_BIAS * 4; }
 
 struct LlParams {
     const bf16_t* X; int ldx;
@@ -648,10 +650,11 @@ struct LlParams {
     int nsplit, cpp;             // workgroups per row tile, chunks per workgroup
     const float* ln_g; const float* ln_b; float ln_eps;      // LayerNorm / GroupNorm gamma, beta
     const float2* gn_stats; int gn_groups, gn_rpi;           // NORM 2: (mean, rstd) [inst][group], rows per instance (% 128 == 0)
-};
+    const bf16_t* R; int ldr;                                // RES: out = R + n W^T + bias (R may be O: every element is read and
+};                                                           // written by the same lane of the same workgroup)
 
-// NORM 0: none, 1: LayerNorm over the row, 2: GroupNorm with known statistics; K = 320 KH
-template <int NORM, int KH>
+// NORM 0: none, 1: LayerNorm over the row, 2: GroupNorm with known statistics; K = 320 KH; RES: residual operand
+template <int NORM, int KH, bool RES = false>
 __global__ __launch_bounds__(256, KH == 1 ? 3 : 2)
 void norm_linear_kernel(const LlParams p) {
     constexpr int KD = FD * KH;
@@ -700,12 +703,16 @@ void norm_linear_kernel(const LlParams p) {
     // ---- X fragments of this wave's 32 rows (B operand: lane (row fr, half fh) holds k = 16 kk + 8 fh .. + 7)
     bf16x8_t xf[KD / 16];
     float* const lns = reinterpret_cast<float*>(smem + 2 * LW_STAGE + 4 * 2048);
+    float* const bls = lns + 2 * KD;
+    const bool bias_lds = p.bias != nullptr && p.N <= LL_BIAS;
     {
         int mr = m0 + fr;
         if (mr >= p.M) mr = p.M - 1;
         const bf16_t* xr = p.X + (size_t)mr * p.ldx + fh * 8;
 #pragma unroll
         for (int kk = 0; kk < KD / 16; ++kk) xf[kk] = *reinterpret_cast<const bf16x8_t*>(xr + kk * 16);
+        // the bias in LDS: as global loads in the chunk epilogue they were two exposed round trips per 20 MFMAs
+        if (bias_lds) for (int i = tid; i < p.N; i += 256) bls[i] = p.bias[i];
         if constexpr (NORM == 1) {
             for (int i = tid; i < KD; i += 256) { lns[i] = p.ln_g[i]; lns[KD + i] = p.ln_b[i]; }
         } else if constexpr (NORM == 2) {
@@ -729,6 +736,7 @@ void norm_linear_kernel(const LlParams p) {
         f32x16_t acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        u32x4_t rres[2];                              // RES: this lane's two 16-byte pieces of the chunk's residual rows
 #pragma unroll
         for (int h = 0; h < KH; ++h) {
             if (c > c_begin || h > 0) {
@@ -738,6 +746,18 @@ void norm_linear_kernel(const LlParams p) {
                 else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
                 asm volatile("" ::: "memory");
+            }
+            if constexpr (RES) {
+                // the residual rows of this chunk, in the coalesced pattern of the stores (16 rows x 64 B per instruction),
+                // requested a chunk's MFMAs ahead of the epilogue that adds them
+                if (h == 0) {
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) {
+                        int m = m0 + t * 16 + (lane >> 2);
+                        if (m >= p.M) m = p.M - 1;
+                        rres[t] = *reinterpret_cast<const u32x4_t*>(p.R + (size_t)m * p.ldr + c * LCH + (lane & 3) * 8);
+                    }
+                }
             }
             const char* s1 = smem + slot * LW_STAGE;
             bf16x8_t wr[PD];
@@ -761,16 +781,33 @@ void norm_linear_kernel(const LlParams p) {
         // ---- chunk epilogue: + bias, bf16, row-major 16-byte stores through the wave-private patch (32 rows x 64 B)
         {
             const int n0 = c * LCH;
+            const int rrow = lane >> 2, rc = lane & 3;
+            if constexpr (RES) {
+                // residual through the patch the other way round: row-major in, accumulator layout out - the sum is formed in
+                // fp32 and rounded to bf16 once, as the tile GEMM's residual epilogue does (one wave's LDS operations execute in
+                // order: no barrier)
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const int r = t * 16 + rrow;
+                    *reinterpret_cast<u32x4_t*>(ebuf + r * 64 + ((rc ^ ((r >> 1) & 3)) << 4)) = rres[t];
+                }
+            }
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 float4 bv = {0.f, 0.f, 0.f, 0.f};
-                if (p.bias) bv = *reinterpret_cast<const float4*>(p.bias + n0 + 8 * q + 4 * fh);
+                if (bias_lds) bv = *reinterpret_cast<const float4*>(bls + n0 + 8 * q + 4 * fh);
+                else if (p.bias) bv = *reinterpret_cast<const float4*>(p.bias + n0 + 8 * q + 4 * fh);
+                uint2* const slot = reinterpret_cast<uint2*>(ebuf + fr * 64 + (((2 * q + fh) ^ (((fr >> 1) & 3) << 1)) << 3));
+                if constexpr (RES) {
+                    const uint2 rv = *slot;
+                    bv.x += __uint_as_float(rv.x << 16); bv.y += __uint_as_float(rv.x & 0xffff0000u);
+                    bv.z += __uint_as_float(rv.y << 16); bv.w += __uint_as_float(rv.y & 0xffff0000u);
+                }
                 uint2 pk;
                 pk.x = pack_bf2(acc[4 * q] + bv.x, acc[4 * q + 1] + bv.y);
                 pk.y = pack_bf2(acc[4 * q + 2] + bv.z, acc[4 * q + 3] + bv.w);
-                *reinterpret_cast<uint2*>(ebuf + fr * 64 + (((2 * q + fh) ^ (((fr >> 1) & 3) << 1)) << 3)) = pk;
+                *slot = pk;
             }
-            const int rrow = lane >> 2, rc = lane & 3;
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
                 const int r = t * 16 + rrow;
@@ -1228,11 +1265,11 @@ extern "C" int dc_ff_geglu_proj_fused320(const uint16_t* x, int ldx, const float
                            ldo, M, (hipStream_t)stream_);
 }
 
-template <int NORM, int KH>
+template <int NORM, int KH, bool RES = false>
 static int launch_norm_linear_t(const LlParams& p, dim3 grid, hipStream_t stream) {
     static DcLdsOnce lds_once;
-    if (const int e = lds_once.ensure(reinterpret_cast<const void*>(&norm_linear_kernel<NORM, KH>), ll_lds(KH))) return e;
-    hipLaunchKernelGGL((norm_linear_kernel<NORM, KH>), grid, dim3(256), ll_lds(KH), stream, p);
+    if (const int e = lds_once.ensure(reinterpret_cast<const void*>(&norm_linear_kernel<NORM, KH, RES>), ll_lds(KH))) return e;
+    hipLaunchKernelGGL((norm_linear_kernel<NORM, KH, RES>), grid, dim3(256), ll_lds(KH), stream, p);
     DC_CHECK_LAUNCH();
     return 0;
 }
@@ -1246,6 +1283,7 @@ static int launch_norm_linear(int norm, int K, LlParams& p, hipStream_t stream) 
     p.nsplit = nsplit;
     p.cpp = (nch + nsplit - 1) / nsplit;
     const dim3 grid(tiles * nsplit);
+    if (p.R) return K == FD ? launch_norm_linear_t<0, 1, true>(p, grid, stream) : launch_norm_linear_t<0, 2, true>(p, grid, stream);
     if (K == FD) {
         if (norm == 1) return launch_norm_linear_t<1, 1>(p, grid, stream);
         if (norm == 2) return launch_norm_linear_t<2, 1>(p, grid, stream);
@@ -1264,7 +1302,20 @@ extern "C" int dc_ln_linear(const uint16_t* x, int ldx, int K, const float* ln_g
     LlParams p;
     p.X = x; p.ldx = ldx; p.W = w; p.bias = bias; p.O = out; p.ldo = ldo; p.M = M; p.N = N;
     p.ln_g = ln_gamma; p.ln_b = ln_beta; p.ln_eps = ln_eps; p.gn_stats = nullptr; p.gn_groups = 1; p.gn_rpi = FBM;
+    p.R = nullptr; p.ldr = 0;
     return launch_norm_linear(ln_gamma ? 1 : 0, K, p, (hipStream_t)stream_);
+}
+
+extern "C" int dc_linear_residual(const uint16_t* x, int ldx, int K, const uint16_t* w, const float* bias,
+                                  const uint16_t* residual, int ldr, uint16_t* out, int ldo, int M, int N, void* stream_) {
+    if (!x || !w || !out || !residual) return DC_ERR_ARG;
+    if ((K != FD && K != 2 * FD) || M < 1 || N < LCH || N % LCH || ldx % 8 || ldo % 8 || ldr % 8) return DC_ERR_SHAPE;
+    if (((uintptr_t)x | (uintptr_t)out | (uintptr_t)w | (uintptr_t)residual) % 16) return DC_ERR_SHAPE;
+    LlParams p;
+    p.X = x; p.ldx = ldx; p.W = w; p.bias = bias; p.O = out; p.ldo = ldo; p.M = M; p.N = N;
+    p.ln_g = nullptr; p.ln_b = nullptr; p.ln_eps = 0.f; p.gn_stats = nullptr; p.gn_groups = 1; p.gn_rpi = FBM;
+    p.R = residual; p.ldr = ldr;
+    return launch_norm_linear(0, K, p, (hipStream_t)stream_);
 }
 
 extern "C" int dc_gn_linear(const uint16_t* x, int ldx, int K, const float* gamma, const float* beta, const float* stats,
@@ -1278,6 +1329,7 @@ extern "C" int dc_gn_linear(const uint16_t* x, int ldx, int K, const float* gamm
     p.X = x; p.ldx = ldx; p.W = w; p.bias = bias; p.O = out; p.ldo = ldo; p.M = M; p.N = N;
     p.ln_g = gamma; p.ln_b = beta; p.ln_eps = 0.f;
     p.gn_stats = reinterpret_cast<const float2*>(stats); p.gn_groups = groups; p.gn_rpi = rows_per_inst;
+    p.R = nullptr; p.ldr = 0;
     return launch_norm_linear(2, K, p, (hipStream_t)stream_);
 }
 

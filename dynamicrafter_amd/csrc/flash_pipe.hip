@@ -53,7 +53,8 @@ constexpr int FP_KBYTES = 64 * 128;
 constexpr int FP_VBYTES = 64 * FP_VLD;
 constexpr int FP_STAGE = FP_KBYTES + FP_VBYTES;     // 20 KB
 constexpr int FP_NSTAGE = 4;
-constexpr int FP_LDS = FP_NSTAGE * FP_STAGE;        // 80 KB
+constexpr int FP_RING = FP_NSTAGE * FP_STAGE;       // 80 KB
+constexpr int FP_LDS = FP_RING + 64;                // + the arrival counter of the ring
 
 template <int V> using ic = std::integral_constant<int, V>;
 
@@ -252,12 +253,13 @@ void flash_attn_d64_pipe_kernel(const bf16_t* __restrict__ q, const bf16_t* __re
     // top). The memory instructions sit in the last NL gaps (the row-sum gaps when the step has PV), spread evenly in this
     // order: the next step's four K fragments (kn: their addresses, NK: needed) and eight V^T fragment halves (vn, NV), then,
     // RING 1 (even steps of the loop), the four LDS stores of tile T+2 (loaded an iteration ago) into the stage of tile T-2 and
-    // the four global loads of tile T+3 into the same staging registers. RING 2 (odd steps): `s_waitcnt lgkmcnt(0)` + the
-    // workgroup barrier in front of those gaps (everything the wave has requested has long returned, so the wait is free):
-    // behind it every wave's stores of tile T+2 are complete - it is first requested right there - and its requests of tile
-    // T-1 have returned.
+    // the four global loads of tile T+3 into the same staging registers, then the wave's arrival. RING 2 (odd steps): in front
+    // of those gaps the check that all four waves have arrived (`tile` = 4 (T + 1)): then every wave's stores of tile T+2 are
+    // complete - it is first requested right there - and its requests of tile T-1 have returned.
     // In-gap order: the MFMA, this gap's two v_exp_f32, then the pack of the PREVIOUS gap's exponentials, v_max3 in between -
     // no statement directly follows one that produced an operand of it (hipcc pads such pairs of asm statements).
+    __attribute__((address_space(3))) int* const ring_cnt = (__attribute__((address_space(3))) int*)(smem + FP_RING);
+    int seen = 0;
     auto step = [&](auto PAR_, auto TR_, auto DEC_, auto QK_, auto MX_, auto EX_, auto PV_, auto NK_, auto NV_, auto RING_,
                     const unsigned (&kn)[4], int knpar, unsigned vn, int vnpar, int tile, int stage) __attribute__((always_inline)) {
         constexpr int PAR = decltype(PAR_)::value, RING = decltype(RING_)::value;
@@ -283,7 +285,22 @@ void flash_attn_d64_pipe_kernel(const bf16_t* __restrict__ q, const bf16_t* __re
             // ---- memory instructions of this gap
             const int j = g - (NG - NL);              // 0 .. NL-1 in the last NL gaps
 #ifndef FP_DBG_NOBAR
+#ifdef FP_HW_BARRIER
             if constexpr (RING == 2) { if (j == 0) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+#else
+            // the ring's synchronisation without s_barrier (which cost ~280 clocks per tile: every wave waits for the slowest at
+            // every tile): a wave ARRIVES by adding 1 to an LDS counter behind its stores of tile T+2 (one wave's LDS operations
+            // execute in order: whoever sees the add sees the stores, and the wave's own requests of older tiles have returned),
+            // and a step later, before it requests tile T+2, checks that all four have arrived at this iteration - normally
+            // long true; the value is requested four gaps ahead of the check
+            if constexpr (RING == 2) {
+                if (g == NEX - 4) seen = *(volatile __attribute__((address_space(3))) int*)ring_cnt;
+                if (j == 0) {
+                    while (__builtin_amdgcn_readfirstlane(seen) < tile) seen = *(volatile __attribute__((address_space(3))) int*)ring_cnt;
+                    asm volatile("" ::: "memory");
+                }
+            }
+#endif
 #endif
             if constexpr (NSLOT > 0) {
 #pragma unroll
@@ -304,6 +321,10 @@ void flash_attn_d64_pipe_kernel(const bf16_t* __restrict__ q, const bf16_t* __re
 #endif
                 }
             }
+#if !defined(FP_DBG_NOBAR) && !defined(FP_HW_BARRIER)
+            // arrival: behind the last of this step's LDS stores (the slots above)
+            if constexpr (RING == 1) { if (g == NG - 1 && lane == 0) __hip_atomic_fetch_add(ring_cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+#endif
             // ---- the matrix instruction of this gap
             if (g < NQK) {
                 if constexpr (QK) {
@@ -412,7 +433,13 @@ void flash_attn_d64_pipe_kernel(const bf16_t* __restrict__ q, const bf16_t* __re
 #pragma unroll
             for (int j = 0; j < 4; ++j) load_piece(2, j);
         }
+        if (tid == 0) *ring_cnt = 0;
         __syncthreads();
+#ifdef FP_STAGGER
+        // waves that run the same program in step hit the LDS and the issue ports together; the arrival counter tolerates
+        // a skew of up to one step, so the waves can be started a fraction of a step apart (wave w sleeps w * FP_STAGGER * 64 clocks)
+        for (int i = 0; i < wave; ++i) __builtin_amdgcn_s_sleep(FP_STAGGER);
+#endif
         unsigned ka[4], kb2[4], va, vb2;         // K / V fragment addresses of two ring stages
         auto set_addr = [&](unsigned (&kx)[4], unsigned& vx, int kst, int vst) __attribute__((always_inline)) {
 #pragma unroll
@@ -438,7 +465,7 @@ void flash_attn_d64_pipe_kernel(const bf16_t* __restrict__ q, const bf16_t* __re
             set_addr(ka, va, (T + 1) & 3, T & 3);            // this iteration's second halves: K(T+1) rows 32.., V(T) rows 32..
             set_addr(kb2, vb2, (T + 2) & 3, (T + 1) & 3);    // the next iteration's first halves: K(T+2), V(T+1)
             step(ic<0>{}, TRACK{}, TRACK{}, T_{}, TRACK{}, EXL{}, T_{}, T_{}, T_{}, ic<1>{}, ka, 1, va, 1, T + 3, (T + 2) & 3);
-            step(ic<1>{}, TRACK{}, TRACK{}, T_{}, TRACK{}, EXL{}, T_{}, T_{}, T_{}, ic<2>{}, kb2, 0, vb2, 0, 0, 0);
+            step(ic<1>{}, TRACK{}, TRACK{}, T_{}, TRACK{}, EXL{}, T_{}, T_{}, T_{}, ic<2>{}, kb2, 0, vb2, 0, 4 * (T + 1), 0);
         }
 #ifdef FP_STAMPS
         if (tid == 0) {

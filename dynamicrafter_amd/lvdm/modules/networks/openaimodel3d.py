@@ -27,6 +27,7 @@ import os
 _BF16 = torch.bfloat16
 _FF_FUSED = os.environ.get("DC_FF_FUSED", "1") != "0"
 _LN_FUSED = os.environ.get("DC_LN_FUSED", "1") != "0"      # A/B switches of the fused kernels in ff_fused.hip
+_LR_FUSED = os.environ.get("DC_LR_FUSED", "1") != "0"      # Linear + residual at K <= 640 in the X-stationary kernel
 _TA_FUSED = os.environ.get("DC_TA_FUSED", "1") != "0"
 _FFP_FUSED = os.environ.get("DC_FFP_FUSED", "1") != "0"
 _TC_FUSED = os.environ.get("DC_TC_FUSED", "1") != "0"
@@ -422,6 +423,13 @@ class UNetModel(nn.Module):
             return ops.ln_linear(h, pw, out, ln=ln, ln_eps=1e-5)
         return ops.gemm(self._ln(h, ln, "ln"), pw, out)
 
+    def _lin_res(self, x, pw, res, out):
+        """out = res + Linear(x) (attention out-projections, proj_out): at dim 320 / 640 and level-0 / level-1 row counts the
+        X-stationary kernel (HBM-bound on x + res + out), otherwise the tile GEMM with the residual through its LDS ring."""
+        if _LR_FUSED and pw.K in _LN_FUSED_K and pw.N % 32 == 0 and x.shape[0] >= _FUSED_MIN_ROWS:
+            return ops.linear_residual(x, pw, res, out)
+        return ops.gemm(x, pw, out, residual=res)
+
     def _gn_linear(self, x, gnw, pw, out, *, n_inst, rpi):
         """Linear(GroupNorm(x)) (eps 1e-6, no activation: the transformers' norm -> proj_in): at dim 320 / 640 and level-0 / level-1
         row counts the statistics pass plus one kernel that normalises in registers, otherwise GroupNorm + GEMM."""
@@ -438,7 +446,7 @@ class UNetModel(nn.Module):
         att = A.get("att", M, Cc, device=dev)
         ops.flash_attn(qkv[:, :Cc], qkv[:, Cc:2 * Cc], qkv[:, 2 * Cc:], att, batch=g["F"], heads=heads, Lq=g["HW"],
                        Lk=g["HW"], scale=0.125)
-        return ops.gemm(att, Wa["out"], h, residual=h)
+        return self._lin_res(att, Wa["out"], h, h)
 
     def _attn_self_temporal(self, Wa, ln, h, g, heads):
         A = self._arena
@@ -447,10 +455,10 @@ class UNetModel(nn.Module):
         if _TA_FUSED and Cc == 320 and g["T"] == 16 and g["HW"] % 8 == 0 and M >= _FUSED_MIN_ROWS:
             # level 0: LayerNorm, q/k/v and the attention over the 16 frames in one kernel - no [M, 960] qkv tensor
             ops.ln_qkv_temporal_attn320(h, ln, Wa["qkv"], att, B=g["B"], T=16, HW=g["HW"], scale=0.125)
-            return ops.gemm(att, Wa["out"], h, residual=h)
+            return self._lin_res(att, Wa["out"], h, h)
         qkv = self._ln_linear(h, ln, Wa["qkv"], A.get("qkv", M, 3 * Cc, device=dev))
         ops.temporal_attn(qkv, att, B=g["B"], T=g["T"], HW=g["HW"], heads=heads, scale=0.125)
-        return ops.gemm(att, Wa["out"], h, residual=h)
+        return self._lin_res(att, Wa["out"], h, h)
 
     def _ff(self, Wb, h, tag="ln"):
         A = self._arena
@@ -469,7 +477,7 @@ class UNetModel(nn.Module):
             return ops.ff_geglu_proj_fused320(h, B_["ff1"], B_["ff2p"], B_["ff2"].bias, W["proj_p"], W["proj_out"].bias, x, out,
                                               ln=B_["norm3"], ln_eps=1e-5)
         h = self._ff(B_, h)
-        return ops.gemm(h, W["proj_out"], out, residual=x)
+        return self._lin_res(h, W["proj_out"], x, out)
 
     def _spatial_pre(self, W, x, g, heads):
         """SpatialTransformer up to and including the self-attention residual: everything that does not see the
@@ -518,7 +526,7 @@ class UNetModel(nn.Module):
         else:
             ops.flash_attn(q, kv[:, :Cc], kv[:, Cc:2 * Cc], att, batch=g["F"], heads=heads, Lq=g["HW"], Lk=nt, scale=0.125,
                            kv_bstride=Lc)
-        h = ops.gemm(att, B_["out2"], h, residual=h)
+        h = self._lin_res(att, B_["out2"], h, h)
         return self._ff_proj(W, h, x, out if out is not None else A.get(out_tag, M, Cc, device=dev))
 
     def _spatial(self, W, x, g, heads, out_tag, out=None):

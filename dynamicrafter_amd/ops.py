@@ -460,6 +460,20 @@ def ln_linear(x, pw, out, ln=None, ln_eps=1e-5):
     return out
 
 
+def linear_residual(x, pw, residual, out):
+    """out = residual + Linear(x) for dim K = 320 / 640 in the X-stationary kernel (pw = PackedWeight.linear, N % 32 == 0);
+    residual may be `out` itself."""
+    _rows(x, "x"); _rows(out, "out"); _rows(residual, "residual")
+    M, K = x.shape[0], pw.K
+    if K not in (320, 640) or pw.N % 32:
+        raise ValueError("linear_residual: K must be 320 or 640 and N a multiple of 32")
+    _need_rows(x, M, K, "x"); _need_rows(out, M, pw.N, "out"); _need_rows(residual, M, pw.N, "residual")
+    _launch("linear_residual", 2.0 * M * pw.N * K, 2.0 * M * (K + 2 * pw.N) + 2.0 * pw.N * K, _hip.lib().dc_linear_residual,
+            _ptr(x), x.stride(0), K, _ptr(pw.w), _ptr(pw.bias), _ptr(residual), residual.stride(0), _ptr(out), out.stride(0),
+            M, pw.N, stream_ptr())
+    return out
+
+
 def ln_qkv_temporal_attn320(x, ln, pw_qkv, out, *, B, T, HW, scale, ln_eps=1e-5):
     """out = temporal self-attention (over the T = 16 frames of a position) of LayerNorm(x), q/k/v projected in the same
     launch; dim 320 = 5 heads x 64; rows ordered (clip, frame, position)."""

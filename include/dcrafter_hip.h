@@ -231,6 +231,15 @@ int dc_groupnorm_stats(const uint16_t* x, int ldx, int C, int groups, int n_inst
 int dc_gn_linear(const uint16_t* x, int ldx, int K, const float* gamma, const float* beta, const float* stats, int groups,
                  int rows_per_inst, const uint16_t* w, const float* bias, uint16_t* out, int ldo, int M, int N, void* stream);
 
+/* out[M,N] = residual + x W^T + bias for K = 320 or 640 (N % 32 == 0; rows bf16, ld % 8 == 0, 16-byte aligned; residual may
+ * alias out): the activation rows of a workgroup stay in registers (the kernel of dc_ln_linear without a norm), the residual
+ * rows are fetched a chunk ahead in the stores' coalesced pattern and added in fp32 (one rounding).
+ *   replaces attn1 / attn2 .to_out[0] + the residual add of BasicTransformerBlock._forward lvdm/modules/attention.py:242-245
+ *   (CrossAttention.forward :143-144) and proj_out + x_in of SpatialTransformer / TemporalTransformer.forward :309-310, :404-412
+ *   at the UNet's levels 0 and 1 */
+int dc_linear_residual(const uint16_t* x, int ldx, int K, const uint16_t* w, const float* bias, const uint16_t* residual, int ldr,
+                       uint16_t* out, int ldo, int M, int N, void* stream);
+
 /* LayerNorm + to_q/k/v + attention over the T = 16 frames of every spatial position for dim 320 (5 heads x 64) in one launch:
  * out[M, 320] = softmax_T(q k^T scale) v, [q | k | v] = LayerNorm(x) wqkv^T, rows ordered (clip, frame, position), M = B*16*HW,
  * HW % 8 == 0. wqkv: bf16 [>= 960][320] (to_q, to_k, to_v rows). The qkv tensor never reaches HBM; bf16 roundings as in

@@ -36,8 +36,11 @@ CFG_DIR = os.path.join(HERE, "..", "dynamicrafter_amd", "configs")
 
 UNET_TOL, UNET_COS = 3e-2, 0.9997
 STEP_TOL = 2.3e-2
-# classifier-free guidance at scale 7.5 amplifies the branch errors (g = 7.5 e_c - 6.5 e_u); provisional bounds until measured
-GUIDED_TOL, GUIDED_STEP_TOL = 0.5, 0.5
+# classifier-free guidance at scale 7.5 amplifies the branch errors (g = 7.5 e_c - 6.5 e_u): measured 4.5e-2 / 4.4e-2 on the guided
+# output at 16x40x64 / 16x32x32 (3x the per-branch 1.5e-2: e_c - e_u is 0.33-0.40 of |e_c| here and carries 4.8e-2), and
+# 2.8e-4 / 5.5e-3 on x_prev of a full step; bounds = 2x measured
+GUIDED_TOL, GUIDED_STEP_TOL = 9e-2, 1.1e-2
+GUIDED_STEP_TOL_T999 = 6e-2       # first executed step (t = 999, zero terminal SNR): x_prev IS the guided, rescaled v-prediction
 AE_MOM_TOL, AE_Z_TOL, AE_DEC_TOL = 3e-2, 1e-2, 2.7e-2
 
 
@@ -86,7 +89,7 @@ def _rnd(*shape, seed):
 
 
 def _run_case(model, ocfg, sd, *, x, cc, ctx, uc_ctx, fs, disc, eta, gr, tag, golden_y=None, golden_t=None,
-              oracle_both=True):
+              oracle_both=True, guided_at_full_size=False):
     """One guided evaluation at full size: batched HIP forward of both branches + one fused DDIM step vs the oracle.
     oracle_both=False (72x128, where one oracle forward costs minutes of host time): the oracle evaluates the cond
     branch; the uncond SLOT of the batched forward is checked by swapping the two contexts and requiring the cond result
@@ -153,6 +156,15 @@ def _run_case(model, ocfg, sd, *, x, cc, ctx, uc_ctx, fs, disc, eta, gr, tag, go
     torch.cuda.synchronize()
     x_prev = run.img.detach().float().cpu()
     guided = None
+    if not oracle_both and guided_at_full_size:
+        t0 = time.perf_counter()
+        ref_u = ounet.unet_forward(sd, ocfg, xin, torch.full((B,), t_step, dtype=torch.long), uc_ctx, fs).reshape(1, B, 4, T, H, W)
+        print(f"[fullsize {tag}] oracle forward of the uncond branch {time.perf_counter() - t0:.1f} s")
+        ref = torch.cat([ref, ref_u], 0)
+        r_u = rel_l2(e[1], ref[1])
+        print(f"[fullsize {tag}] uncond branch: HIP vs oracle rel-L2 {r_u:.3e}")
+        assert r_u < UNET_TOL
+        oracle_both = True
     if oracle_both:
         # classifier-free guidance amplifies the (uncorrelated) errors of the two branches: g = e_u + 7.5 (e_c - e_u) =
         # 7.5 e_c - 6.5 e_u. Measured here on the guided model output and on x_prev of a full HIP step against the full
@@ -200,7 +212,7 @@ def test_unet_72x128_config3(model_v):
     ctx, uc_ctx = _rnd(B, 77 + 16 * T, 1024, seed=303), _rnd(B, 77 + 16 * T, 1024, seed=304)
     fs = torch.tensor([10])
     out = _run_case(model, ocfg, sd, x=x, cc=cc, ctx=ctx, uc_ctx=uc_ctx, fs=fs, disc="uniform_trailing", eta=1.0, gr=0.7,
-                    tag="1024", oracle_both=False)
+                    tag="1024", oracle_both=False, guided_at_full_size=True)
     # the fused update is checked from the HIP uncond output + the oracle's cond output: isolates the step arithmetic at
     # this size from the (separately bounded) UNet error of the second branch
     xp = _oracle_step("1024", [out["ref"][0], out["e"][1]], x, out["noises"][0], out["S"], "uniform_trailing", 1.0, 0.7,
@@ -208,6 +220,8 @@ def test_unet_72x128_config3(model_v):
     r = rel_l2(out["x_prev"], xp)
     print(f"[fullsize 1024] fused DDIM step x_prev vs oracle rel-L2 {r:.3e}")
     assert r < STEP_TOL
+    # and the whole guided step, both branches from both sides, at the benchmarked size
+    assert out["guided"]["g"] < GUIDED_TOL and out["guided"]["x_prev"] < GUIDED_STEP_TOL_T999
 
 
 def test_unet_40x64_config2_and_5(model_v):

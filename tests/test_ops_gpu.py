@@ -788,6 +788,40 @@ def test_ln_linear_vs_layernorm_plus_gemm(ops, M, N, K):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("M,N,K", [(4096, 320, 320), (1000, 320, 320), (3333, 64, 320), (36864, 640, 640), (777, 640, 640),
+                                   (131, 1280, 640)])
+def test_linear_residual_vs_gemm_with_residual(ops, M, N, K):
+    """dc_linear_residual (X-stationary kernel, residual fetched in the stores' pattern and added in fp32) = dc_gemm_conv with
+    a residual operand (bit for bit: same fp32 sum, one rounding) = torch fp32; in place (residual is the output buffer), into
+    a column slice of a wider buffer, and with a ragged last tile."""
+    g = torch.Generator().manual_seed(M * 3 + N)
+    x = (torch.randn(M, K, generator=g)).to(torch.bfloat16)
+    w = torch.randn(N, K, generator=g) * K ** -0.5
+    b = torch.randn(N, generator=g) * 0.1
+    r = (torch.randn(M, N, generator=g) * 2).to(torch.bfloat16)
+    ref = r.float() + torch.nn.functional.linear(x.float(), w, b)
+    pw = ops.PackedWeight.linear(w, b, DEV)
+    xd, rd = x.to(DEV), r.to(DEV)
+    want = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+    ops.gemm(xd, pw, want, residual=rd)
+    out = torch.full((M, N), 7.0, dtype=torch.bfloat16, device=DEV)
+    ops.linear_residual(xd, pw, rd, out)
+    e_new, e_old, d = rel_l2(out.float().cpu(), ref), rel_l2(want.float().cpu(), ref), rel_l2(out, want)
+    print(f"\n[linear_residual {M}x{N}x{K}] vs fp32: X-stationary {e_new:.2e}, tile GEMM {e_old:.2e}; between them {d:.2e}")
+    assert e_new < 2.6e-3                                # one bf16 rounding of the fp32 sum (measured 1.7e-3)
+    assert d < 3e-3                                      # two roundings of sums that differ in the order of the fp32 adds
+    inplace = rd.clone()
+    ops.linear_residual(xd, pw, inplace, inplace)
+    assert torch.equal(inplace, out)
+    wide = torch.full((M, N + 64), 3.0, dtype=torch.bfloat16, device=DEV)
+    ops.linear_residual(xd, pw, rd, wide[:, 32:32 + N])
+    assert torch.equal(wide[:, 32:32 + N], out) and (wide[:, :32] == 3).all() and (wide[:, 32 + N:] == 3).all()
+    pw0 = ops.PackedWeight.linear(w, None, DEV)
+    ops.linear_residual(xd, pw0, rd, out)
+    assert rel_l2(out.float().cpu(), r.float() + torch.nn.functional.linear(x.float(), w)) < 4e-3
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("n_inst,rpi,N,K", [(3, 256, 320, 320), (2, 9216, 320, 320), (5, 128, 64, 320), (32, 2304, 640, 640),
                                              (3, 384, 96, 640)])
 def test_gn_linear_vs_groupnorm_plus_gemm(ops, n_inst, rpi, N, K):

@@ -27,6 +27,10 @@ for v in "$@"; do
     st_nolds_nostage) build st_nolds_nostage "-DFP_STAMPS -DFP_DBG_NOLDS -DFP_DBG_NOSTAGE -DFP_DBG_NOBAR" ;;
     st_mfma) build st_mfma "-DFP_STAMPS -DFP_DBG_NOEX -DFP_DBG_NOLDS -DFP_DBG_NOSTAGE -DFP_DBG_NOBAR" ;;
     st_nobar) build st_nobar "-DFP_STAMPS -DFP_DBG_NOBAR" ;;
+    st_hwbar) build st_hwbar "-DFP_STAMPS -DFP_HW_BARRIER" ;;
+    st_stag2) build st_stag2 "-DFP_STAMPS -DFP_STAGGER=2" ;;
+    st_stag4) build st_stag4 "-DFP_STAMPS -DFP_STAGGER=4" ;;
+    st_stag8) build st_stag8 "-DFP_STAMPS -DFP_STAGGER=8" ;;
     st_noload) build st_noload "-DFP_STAMPS -DFP_DBG_NOLOAD" ;;
     st_nostore) build st_nostore "-DFP_STAMPS -DFP_DBG_NOSTORE" ;;
     st_vinstep) build st_vinstep "-DFP_STAMPS -DFP_V_IN_STEP" ;;
