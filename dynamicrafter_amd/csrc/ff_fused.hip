@@ -1066,6 +1066,8 @@ void gn_silu_tconv_kernel(const TcParams p) {
     const unsigned lds_base = (unsigned)(unsigned long)((lds_char_t*)smem);
     char* const ebuf = smem + 2 * LW_STAGE + wave * 2048;
     float* const lns = reinterpret_cast<float*>(smem + 2 * LW_STAGE + 4 * 2048);
+    float* const bls = lns + 2 * KD;                     // the bias in LDS (as in norm_linear_kernel)
+    const bool bias_lds = KH == 1 && p.N <= LL_BIAS;     // (C = 640 sits at 256 registers: it keeps its loads in the epilogue)
     const int tile = (int)blockIdx.x / p.nsplit, part = (int)blockIdx.x - tile * p.nsplit;
     const int gpb = p.HW >> 3;
     const int b = tile / gpb, p0 = (tile - b * gpb) * 8 + 2 * wave;
@@ -1118,6 +1120,7 @@ void gn_silu_tconv_kernel(const TcParams p) {
             const float a = p.gn_g[i] * st.y;
             lns[i] = a; lns[KD + i] = p.gn_b[i] - st.x * a;
         }
+        if (bias_lds) for (int i = tid; i < p.N; i += 256) bls[i] = p.bias[i];
     }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
@@ -1129,15 +1132,25 @@ void gn_silu_tconv_kernel(const TcParams p) {
     int slot = 0;
     for (int c = c_begin; c < c_end; ++c) {
         f32x16_t out, y;
+        u32x4_t rres[2];
 #pragma unroll
         for (int j = 0; j < NS; ++j) {
             const int jt = j / KH, h = j % KH;            // jt 0: tap 1 (centre) -> out; 1: tap 0 (frame - 1); 2: tap 2 (frame + 1)
             if (c > c_begin || j > 0) {
                 // this stage was issued during the previous one, in front of the loads / stores that closed a chunk
-                if (j == 0) { if (RES) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); }
+                if (j == 0) { if (RES && KH != 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); }
                 else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
                 asm volatile("" ::: "memory");
+            }
+            if constexpr (RES && KH == 1) {
+                // the residual rows of this chunk in the stores' coalesced pattern, requested a chunk's MFMAs ahead of the
+                // epilogue (as loads inside the epilogue they were an exposed round trip per chunk)
+                if (j == 0) {
+#pragma unroll
+                    for (int t = 0; t < 2; ++t)
+                        rres[t] = *reinterpret_cast<const u32x4_t*>(p.R + grow(t * 16 + (lane >> 2)) * p.ldr + c * LCH + (lane & 3) * 8);
+                }
             }
             const char* s1 = smem + slot * LW_STAGE;
             f32x16_t& acc = jt == 0 ? out : y;
@@ -1177,30 +1190,39 @@ void gn_silu_tconv_kernel(const TcParams p) {
         // ---- chunk epilogue: + bias, bf16, (+ residual), row-major through the wave-private patch; rows scattered back
         {
             const int n0 = c * LCH;
+            const int rrow = lane >> 2, rc = lane & 3;
+            if constexpr (RES) {
+                if constexpr (KH != 1) {
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) rres[t] = *reinterpret_cast<const u32x4_t*>(p.R + grow(t * 16 + rrow) * p.ldr + n0 + rc * 8);
+                }
+                // residual through the patch the other way round (row-major in, accumulator layout out): the sum is formed in
+                // fp32 and rounded once
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const int r = t * 16 + rrow;
+                    *reinterpret_cast<u32x4_t*>(ebuf + r * 64 + ((rc ^ ((r >> 1) & 3)) << 4)) = rres[t];
+                }
+            }
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const float4 bv = *reinterpret_cast<const float4*>(p.bias + n0 + 8 * q + 4 * fh);
+                float4 bv = bias_lds ? *reinterpret_cast<const float4*>(bls + n0 + 8 * q + 4 * fh)
+                                     : *reinterpret_cast<const float4*>(p.bias + n0 + 8 * q + 4 * fh);
+                uint2* const slot2 = reinterpret_cast<uint2*>(ebuf + fr * 64 + (((2 * q + fh) ^ (((fr >> 1) & 3) << 1)) << 3));
+                if constexpr (RES) {
+                    const uint2 rv = *slot2;
+                    bv.x += __uint_as_float(rv.x << 16); bv.y += __uint_as_float(rv.x & 0xffff0000u);
+                    bv.z += __uint_as_float(rv.y << 16); bv.w += __uint_as_float(rv.y & 0xffff0000u);
+                }
                 uint2 pk;
                 pk.x = pack_bf2(out[4 * q] + bv.x, out[4 * q + 1] + bv.y);
                 pk.y = pack_bf2(out[4 * q + 2] + bv.z, out[4 * q + 3] + bv.w);
-                *reinterpret_cast<uint2*>(ebuf + fr * 64 + (((2 * q + fh) ^ (((fr >> 1) & 3) << 1)) << 3)) = pk;
-            }
-            const int rrow = lane >> 2, rc = lane & 3;
-            u32x4_t rres[2];
-            if constexpr (RES) {
-#pragma unroll
-                for (int t = 0; t < 2; ++t) rres[t] = *reinterpret_cast<const u32x4_t*>(p.R + grow(t * 16 + rrow) * p.ldr + n0 + rc * 8);
+                *slot2 = pk;
             }
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
                 const int r = t * 16 + rrow;
-                u32x4_t d = *reinterpret_cast<const u32x4_t*>(ebuf + r * 64 + ((rc ^ ((r >> 1) & 3)) << 4));
-                if constexpr (RES) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        d[e] = pack_bf2(__uint_as_float(d[e] << 16) + __uint_as_float(rres[t][e] << 16),
-                                        __uint_as_float(d[e] & 0xffff0000u) + __uint_as_float(rres[t][e] & 0xffff0000u));
-                }
+                const u32x4_t d = *reinterpret_cast<const u32x4_t*>(ebuf + r * 64 + ((rc ^ ((r >> 1) & 3)) << 4));
                 *reinterpret_cast<u32x4_t*>(p.O + grow(r) * p.ldo + n0 + rc * 8) = d;
             }
         }
