@@ -31,7 +31,9 @@ _LR_FUSED = os.environ.get("DC_LR_FUSED", "1") != "0"      # Linear + residual a
 _TA_FUSED = os.environ.get("DC_TA_FUSED", "1") != "0"
 _FFP_FUSED = os.environ.get("DC_FFP_FUSED", "1") != "0"
 _TC_FUSED = os.environ.get("DC_TC_FUSED", "1") != "0"
-_FUSED_MIN_ROWS = int(os.environ.get("DC_FUSED_MIN_ROWS", "32768"))     # below this the tile GEMMs + norm kernels are used
+# below this row count the tile GEMMs + norm kernels are used (the 1024 config's level-0/1 tensors have >= 73728 rows; at the
+# 512 / 256 configs level 1 has 20480 / 8192: fused kernels measured 42.1 -> 41.8 and 24.1 -> 23.4 ms per step there)
+_FUSED_MIN_ROWS = int(os.environ.get("DC_FUSED_MIN_ROWS", "4096"))
 _LN_FUSED_K = tuple(int(k) for k in os.environ.get("DC_LN_FUSED_K", "320,640").split(","))
 C_IN_PAD = 64   # conv_in consumes the 8 latent+concat channels zero-padded to one 64-wide K slice
 

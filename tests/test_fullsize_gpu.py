@@ -40,7 +40,8 @@ STEP_TOL = 2.3e-2
 # output at 16x40x64 / 16x32x32 (3x the per-branch 1.5e-2: e_c - e_u is 0.33-0.40 of |e_c| here and carries 4.8e-2), and
 # 2.8e-4 / 5.5e-3 on x_prev of a full step; bounds = 2x measured
 GUIDED_TOL, GUIDED_STEP_TOL = 9e-2, 1.1e-2
-GUIDED_STEP_TOL_T999 = 6e-2       # first executed step (t = 999, zero terminal SNR): x_prev IS the guided, rescaled v-prediction
+GUIDED_STEP_TOL_T999 = 2.3e-2     # first executed step (t = 999, zero terminal SNR): x_prev IS the guided, rescaled v-prediction
+                                  # (measured 1.12e-2 at 16x72x128 with both branches from both sides; guided output 4.3e-2)
 AE_MOM_TOL, AE_Z_TOL, AE_DEC_TOL = 3e-2, 1e-2, 2.7e-2
 
 

@@ -3,8 +3,8 @@
 #   <tag>_bench1024_guard.json    the same workload with DC_ARENA_GUARD=1 (scratch sentinels verified at full size)
 #   <tag>_bench512.json / 256     the other released configs (parity-test cases; builder-run numbers)
 #   tools/profile_step.sh         rocprofv3 kernel stats + PMC traffic table
-#   tools/pmc_one_gemm.sh         PMC counters of the level-0 linear [294912 x 320 x 320]
-TAG=${1:-r02}
+#   tools/pmc_one_gemm.sh         PMC counters of single kernels: flash attention 32x5x9216, the fused level-0 kernels (one_fused.py)
+TAG=${1:-r03}
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/$TAG
 mkdir -p $O
@@ -20,4 +20,8 @@ python bench.py --res 256 --steps 20 --warmup 2 > $O/${TAG}_bench256.json 2> $O/
 grep -E "timed|cpu_baseline: oracle" $O/bench256.log
 bash tools/profile_step.sh $TAG > $O/profile.log 2>&1 || { tail -5 $O/profile.log; exit 1; }
 head -30 $O/${TAG}_traffic_by_kernel.md
-bash tools/pmc_one_gemm.sh lin320 lin 320 320 72 128 > $O/pmc.log 2>&1; python tools/pmc_summary.py $R/gpurun_out/pmc_lin320 > $O/${TAG}_pmc_lin320.txt 2>&1; tail -25 $O/${TAG}_pmc_lin320.txt
+# PMC counters (MFMA busy, wait / issue split, L1 pending stalls, L2 <-> memory requests) of single kernels
+PMC_SCRIPT=one_flash.py bash tools/pmc_one_gemm.sh flash 32 5 9216 9216 > $O/pmc_flash.log 2>&1; python tools/pmc_summary.py $R/gpurun_out/pmc_flash > $O/${TAG}_pmc_flash.txt 2>&1; tail -12 $O/${TAG}_pmc_flash.txt
+for k in ff tconv lnlin linres; do
+  PMC_SCRIPT=one_fused.py bash tools/pmc_one_gemm.sh $k $k > $O/pmc_$k.log 2>&1; python tools/pmc_summary.py $R/gpurun_out/pmc_$k > $O/${TAG}_pmc_$k.txt 2>&1; tail -8 $O/${TAG}_pmc_$k.txt
+done
