@@ -262,27 +262,41 @@ __global__ __launch_bounds__(256, 2) void flash_attn_d64_kernel(
 #pragma unroll
                 for (int r = 0; r < 16; ++r) oacc[x][d][r] = ofin[x][d][r];
         }
-        if (qrow[x] < Lq) {
-            bf16_t* orow = ob + (size_t)qrow[x] * ldo;
+        if (!DUAL && accumulate) {
+            if (qrow[x] < Lq) {
+                bf16_t* orow = ob + (size_t)qrow[x] * ldo;
+#pragma unroll
+                for (int db = 0; db < 2; ++db)
+#pragma unroll
+                    for (int qd = 0; qd < 4; ++qd) {
+                        const int d = db * 32 + 8 * qd + 4 * fh;
+                        uint2* dst = reinterpret_cast<uint2*>(orow + d);
+                        const uint2 old = *dst;
+                        uint2 pk;
+                        pk.x = pack_bf2(__uint_as_float(old.x << 16) + acc_scale * (oacc[x][db][4 * qd + 0] * inv),
+                                        __uint_as_float(old.x & 0xffff0000u) + acc_scale * (oacc[x][db][4 * qd + 1] * inv));
+                        pk.y = pack_bf2(__uint_as_float(old.y << 16) + acc_scale * (oacc[x][db][4 * qd + 2] * inv),
+                                        __uint_as_float(old.y & 0xffff0000u) + acc_scale * (oacc[x][db][4 * qd + 3] * inv));
+                        *dst = pk;
+                    }
+            }
+        } else {
+            // a row's channels 8 qd .. 8 qd + 7 are split over its two lanes: one v_permlane32_swap per dword between the
+            // groups qd and qd + 1 turns eight 8-byte stores per row block into four 16-byte ones (issue-bound store tail; with
+            // 93 keys the epilogue is a large part of a cross-attention workgroup)
+            bf16_t* orow = ob + (size_t)(qrow[x] < Lq ? qrow[x] : Lq - 1) * ldo;
 #pragma unroll
             for (int db = 0; db < 2; ++db)
 #pragma unroll
-                for (int qd = 0; qd < 4; ++qd) {
-                    const int d = db * 32 + 8 * qd + 4 * fh;
-                    float v0 = oacc[x][db][4 * qd + 0] * inv, v1 = oacc[x][db][4 * qd + 1] * inv;
-                    float v2 = oacc[x][db][4 * qd + 2] * inv, v3 = oacc[x][db][4 * qd + 3] * inv;
-                    uint2* dst = reinterpret_cast<uint2*>(orow + d);
-                    if (!DUAL && accumulate) {
-                        const uint2 old = *dst;
-                        v0 = __uint_as_float(old.x << 16) + acc_scale * v0;
-                        v1 = __uint_as_float(old.x & 0xffff0000u) + acc_scale * v1;
-                        v2 = __uint_as_float(old.y << 16) + acc_scale * v2;
-                        v3 = __uint_as_float(old.y & 0xffff0000u) + acc_scale * v3;
-                    }
-                    uint2 pk;
-                    pk.x = pack_bf2(v0, v1);
-                    pk.y = pack_bf2(v2, v3);
-                    *dst = pk;
+                for (int qd = 0; qd < 4; qd += 2) {
+                    unsigned a0 = pack_bf2(oacc[x][db][4 * qd + 0] * inv, oacc[x][db][4 * qd + 1] * inv);
+                    unsigned a1 = pack_bf2(oacc[x][db][4 * qd + 2] * inv, oacc[x][db][4 * qd + 3] * inv);
+                    unsigned b0 = pack_bf2(oacc[x][db][4 * qd + 4] * inv, oacc[x][db][4 * qd + 5] * inv);
+                    unsigned b1 = pack_bf2(oacc[x][db][4 * qd + 6] * inv, oacc[x][db][4 * qd + 7] * inv);
+                    const auto r0 = __builtin_amdgcn_permlane32_swap(a0, b0, false, false);
+                    const auto r1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);
+                    u32x4_t pk = {r0[0], r1[0], r0[1], r1[1]};
+                    if (qrow[x] < Lq) *reinterpret_cast<u32x4_t*>(orow + db * 32 + 8 * (qd + fh)) = pk;
                 }
         }
     }
@@ -389,7 +403,7 @@ extern "C" int dc_flash_attn_d64(const uint16_t* q, const uint16_t* k, const uin
     hipStream_t stream = (hipStream_t)stream_;
     if (!q || !k || !v || !o) return DC_ERR_ARG;
     if (batch <= 0 || heads <= 0 || Lq <= 0 || Lk <= 0) return DC_ERR_SHAPE;
-    if (ldq % 8 || ldk % 8 || ldv % 8 || ldo % 4) return DC_ERR_SHAPE;
+    if (ldq % 8 || ldk % 8 || ldv % 8 || ldo % 8 || ((uintptr_t)o & 15)) return DC_ERR_SHAPE;      // 16-byte output stores
     const float c = scale * 1.4426950408889634f;
     // long self-attention: the one-wave-per-SIMD software-pipelined kernel (flash_pipe.hip); DC_FLASH_PIPE=0 keeps the
     // two-waves-per-SIMD kernel below (same-box A/B)
@@ -421,7 +435,7 @@ extern "C" int dc_cross_attn_dual_d64(const uint16_t* q, const uint16_t* k, cons
     hipStream_t stream = (hipStream_t)stream_;
     if (!q || !k || !v || !k2 || !v2 || !o) return DC_ERR_ARG;
     if (batch <= 0 || heads <= 0 || Lq <= 0 || Lk <= 0 || Lk2 <= 0) return DC_ERR_SHAPE;
-    if (ldq % 8 || ldkv % 8 || ldo % 4) return DC_ERR_SHAPE;
+    if (ldq % 8 || ldkv % 8 || ldo % 8 || ((uintptr_t)o & 15)) return DC_ERR_SHAPE;               // 16-byte output stores
     const float c = scale * 1.4426950408889634f;
     const int q_tiles = (Lq + FA_BQ - 1) / FA_BQ;
     const long long nwg = (long long)q_tiles * heads * batch;

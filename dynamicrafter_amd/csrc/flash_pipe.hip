@@ -506,19 +506,23 @@ void flash_attn_d64_pipe_kernel(const bf16_t* __restrict__ q, const bf16_t* __re
 #pragma unroll
     for (int x = 0; x < QB; ++x) {
         const float inv = 1.0f / l_tot[x];
-        if (qrow[x] < Lq) {
-            bf16_t* orow = ob + (size_t)qrow[x] * ldo;
+        // a row's 8 channels 8 qd .. 8 qd + 7 are split over its two lanes (fh = 0 / 1: 4 each). One v_permlane32_swap per
+        // dword between the groups qd and qd + 1 gives the lower lane the 16 contiguous bytes of group qd and the upper lane
+        // those of group qd + 1: 4 16-byte stores per row block instead of 8 8-byte ones (the store tail is issue-bound)
+        bf16_t* orow = ob + (size_t)(qrow[x] < Lq ? qrow[x] : Lq - 1) * ldo;
 #pragma unroll
-            for (int db = 0; db < 2; ++db)
+        for (int db = 0; db < 2; ++db)
 #pragma unroll
-                for (int qd = 0; qd < 4; ++qd) {
-                    const int d = db * 32 + 8 * qd + 4 * fh;
-                    uint2 pk;
-                    pk.x = pack_bf2(O[x][db][4 * qd + 0] * inv, O[x][db][4 * qd + 1] * inv);
-                    pk.y = pack_bf2(O[x][db][4 * qd + 2] * inv, O[x][db][4 * qd + 3] * inv);
-                    *reinterpret_cast<uint2*>(orow + d) = pk;
-                }
-        }
+            for (int qd = 0; qd < 4; qd += 2) {
+                unsigned a0 = pack_bf2(O[x][db][4 * qd + 0] * inv, O[x][db][4 * qd + 1] * inv);
+                unsigned a1 = pack_bf2(O[x][db][4 * qd + 2] * inv, O[x][db][4 * qd + 3] * inv);
+                unsigned b0 = pack_bf2(O[x][db][4 * qd + 4] * inv, O[x][db][4 * qd + 5] * inv);
+                unsigned b1 = pack_bf2(O[x][db][4 * qd + 6] * inv, O[x][db][4 * qd + 7] * inv);
+                const auto r0 = __builtin_amdgcn_permlane32_swap(a0, b0, false, false);
+                const auto r1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);
+                u32x4_t pk = {r0[0], r1[0], r0[1], r1[1]};
+                if (qrow[x] < Lq) *reinterpret_cast<u32x4_t*>(orow + db * 32 + 8 * (qd + fh)) = pk;
+            }
     }
 }
 

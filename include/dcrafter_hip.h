@@ -87,6 +87,7 @@ int dc_layernorm(const uint16_t* x, int ldx, uint16_t* y, int ldy, const float* 
 /* softmax(q k^T * scale) v, head_dim 64, flash-style (no score matrix in HBM).
  * q rows: [batch][Lq] at q + (b*q_bstride + i)*ldq + h*64 ; k/v rows: [batch][Lk] likewise with kv_bstride.
  * accumulate != 0: o += acc_scale * result (image cross-attention branch), else o = result.
+ * All row strides % 8 == 0 and q/k/v/o 16-byte aligned (16-byte loads and stores).
  * replaces: CrossAttention.forward core lvdm/modules/attention.py:101-142 (einsum/softmax/einsum, and the
  *           xformers path :166-207) for spatial self-attention and text / image cross-attention. */
 int dc_flash_attn_d64(const uint16_t* q, const uint16_t* k, const uint16_t* v, uint16_t* o,
