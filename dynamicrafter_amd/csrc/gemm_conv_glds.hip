@@ -988,8 +988,9 @@ int dc_gemm_conv_glds_try(const DcGemmParams& p, hipStream_t stream) {
     }
     static const int persist_conv_maxk = [] { const char* e = getenv("DC_GEMM_PERSIST_CONV_MAXK"); return e ? atoi(e) : 2880; }();
     if (persist && force == 0 && !geglu && !out_f32 && epi16 && (p.mode == 2 || (p.mode == 1 && !p.ups)) &&
-        p.N % 320 == 0 && p.n_pad >= p.N && tiles_m * (p.N / 320) >= 512 && p.K <= persist_conv_maxk)
-        return launch_persist_conv320(p, stream);
+        p.N % 320 == 0 && p.n_pad >= p.N && tiles_m * (p.N / 320) >= (p.mode == 1 ? 1024 : 512) && p.K <= persist_conv_maxk)
+        return launch_persist_conv320(p, stream);      // (3x3 convs with 512..1023 tiles measured faster on the split-K plan:
+                                                       //  [147456x320x2880] 684 vs 572 TF/s, [73728x640x2880] 890 vs 734)
     if (geglu) {
         const int w256 = (n_out % 128 == 0 && p.n_pad >= p.N) ? tiles_m * (n_out / 128) : 0;
         const int w128 = tiles_m * (n_out / 64);
