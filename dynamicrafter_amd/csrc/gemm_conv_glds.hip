@@ -567,8 +567,30 @@ __device__ __forceinline__ void persist_epilogue(f32x16_t (&acc)[2][BN / 64], co
 // its residual rows with nothing else in flight (compiler-counted vmcnt(0)): [294912 x 320 x 320] 198 us vs 129 us
 // without the residual, for 31 us worth of extra bytes. The sum is rounded to bf16 once (EPI 1 rounds the GEMM
 // result, then the sum).
+// Logical tile id -> (row panel, column tile) of the persistent kernels. The 32 workgroups of an XCD work on 32 consecutive
+// logical ids at a time and share a 4 MB L2: column-fastest order makes them 1.6 row panels x all 20 / 40 column tiles of a
+// GEGLU projection - every workgroup streams its own weight tile, 6.5 MB per round through an L2 that keeps none of it
+// (counters: 5.2x the algorithmic bytes). group = 8: blocks of 4 panels x 8 column tiles, so a weight tile is shared by 4
+// and an activation panel by 8 workgroups that run in step (4 + 8 operand streams per round instead of 1.6 + 20).
+__device__ __forceinline__ void persist_tile(int logical, int tiles_m, int tiles_n, int group, int& tm, int& tn) {
+    if (group <= 1 || tiles_n <= group) { tn = logical % tiles_n; tm = logical / tiles_n; return; }
+    const int PG = 32 / group;                          // panels per block
+    const int g = logical / (PG * tiles_n);             // panel group
+    const int r = logical - g * (PG * tiles_n);
+    int pg = tiles_m - g * PG;                          // panels in this group (the last one may have fewer)
+    if (pg > PG) pg = PG;
+    const int full = (tiles_n / group) * (pg * group);  // tiles in full-width column chunks
+    if (r < full) {
+        const int c = r / (pg * group), w = r - c * (pg * group);
+        tn = c * group + w / pg; tm = g * PG + w % pg;
+    } else {
+        const int rr = r - full;
+        tn = (tiles_n / group) * group + rr / pg; tm = g * PG + rr % pg;
+    }
+}
+
 template <int BN, bool GEGLU, int GSTAGES, int EPI, int MODE>
-__global__ __launch_bounds__(GNT) void gemm_persist_kernel(const DcGemmParams p) {
+__global__ __launch_bounds__(GNT) void gemm_persist_kernel(const DcGemmParams p, const int tile_group) {
     static_assert(MODE == 0 || !GEGLU, "GEGLU is a plain-GEMM epilogue");
     static_assert(EPI != 3 || !GEGLU, "the ring residual is a plain bf16 epilogue");
     constexpr bool RES_RING = (EPI == 3);
@@ -616,7 +638,8 @@ __global__ __launch_bounds__(GNT) void gemm_persist_kernel(const DcGemmParams p)
     int i_m0 = 0, i_n0 = 0;     // origin of the issue tile (ring residual)
     auto set_issue_tile = [&](int j) __attribute__((always_inline)) {
         const int logical = xcd_remap((int)blockIdx.x + j * G, ntiles);
-        const int tn = logical % tiles_n, tmi = logical / tiles_n;
+        int tn, tmi;
+        persist_tile(logical, tiles_m, tiles_n, tile_group, tmi, tn);
         const int m0 = tmi * GBM, n0 = tn * BNOUT;
         i_m0 = m0; i_n0 = n0;
 #pragma unroll
@@ -822,7 +845,8 @@ __global__ __launch_bounds__(GNT) void gemm_persist_kernel(const DcGemmParams p)
             c_kt = 0;
             const int logical = xcd_remap((int)blockIdx.x + c_tile * G, ntiles);
             ++c_tile;
-            const int tn = logical % tiles_n, tmi = logical / tiles_n;
+            int tn, tmi;
+            persist_tile(logical, tiles_m, tiles_n, tile_group, tmi, tn);
             const int m0 = tmi * GBM, n0 = tn * BNOUT;
             persist_epilogue<BN, GEGLU, EPI>(acc, p, m0, n0, n_out, wm, wn, lane, smem + GSTAGES * STAGE + wave * 2048);
             zero_acc();
@@ -855,7 +879,9 @@ int launch_persist_epi_st(const DcGemmParams& p, hipStream_t stream, int grid) {
                     : MODE == 1 ? "gemm_persist_kernel<320,conv>" : MODE == 2 ? "gemm_persist_kernel<320,tconv>"
                     : BN == 320 ? (EPI == 1 || EPI == 3 ? "gemm_persist_kernel<320,residual>" : "gemm_persist_kernel<320>")
                     : BN == 128 ? "gemm_persist_kernel<128>" : "gemm_persist_kernel<64>");
-    hipLaunchKernelGGL((gemm_persist_kernel<BN, GEGLU, ST, EPI, MODE>), dim3(grid), dim3(GNT), lds, stream, p);
+    static const int group = [] { const char* e = getenv("DC_GEMM_GROUP"); return e ? atoi(e) : 8; }();
+    hipLaunchKernelGGL((gemm_persist_kernel<BN, GEGLU, ST, EPI, MODE>), dim3(grid), dim3(GNT), lds, stream, p,
+                       (group == 2 || group == 4 || group == 8 || group == 16) ? group : 1);
     DC_CHECK_LAUNCH();
     return 0;
 }

@@ -4,11 +4,14 @@
 #   <tag>_bench512.json / 256     the other released configs (parity-test cases; builder-run numbers)
 #   tools/profile_step.sh         rocprofv3 kernel stats + PMC traffic table
 #   tools/pmc_one_gemm.sh         PMC counters of single kernels: flash attention 32x5x9216, the fused level-0 kernels (one_fused.py)
+# optional second argument: which part (bench | prof | pmc | all): gpurun limits one call to 20 minutes
 TAG=${1:-r03}
+PART=${2:-all}
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/$TAG
 mkdir -p $O
 cd $R
+if [ "$PART" = all ] || [ "$PART" = bench ]; then
 python bench.py --steps 20 --warmup 2 > $O/${TAG}_bench1024.json 2> $O/bench1024.log || { tail -5 $O/bench1024.log; exit 1; }
 cp $O/${TAG}_bench1024.json $O/bench_full.json
 grep -E "timed|AE|cpu_baseline" $O/bench1024.log
@@ -18,10 +21,15 @@ python bench.py --res 512 --steps 20 --warmup 2 > $O/${TAG}_bench512.json 2> $O/
 grep -E "timed|cpu_baseline: oracle" $O/bench512.log
 python bench.py --res 256 --steps 20 --warmup 2 > $O/${TAG}_bench256.json 2> $O/bench256.log || { tail -5 $O/bench256.log; exit 1; }
 grep -E "timed|cpu_baseline: oracle" $O/bench256.log
+fi
+if [ "$PART" = all ] || [ "$PART" = prof ]; then
 bash tools/profile_step.sh $TAG > $O/profile.log 2>&1 || { tail -5 $O/profile.log; exit 1; }
 head -30 $O/${TAG}_traffic_by_kernel.md
+fi
+if [ "$PART" = all ] || [ "$PART" = pmc ]; then
 # PMC counters (MFMA busy, wait / issue split, L1 pending stalls, L2 <-> memory requests) of single kernels
 PMC_SCRIPT=one_flash.py bash tools/pmc_one_gemm.sh flash 32 5 9216 9216 > $O/pmc_flash.log 2>&1; python tools/pmc_summary.py $R/gpurun_out/pmc_flash > $O/${TAG}_pmc_flash.txt 2>&1; tail -12 $O/${TAG}_pmc_flash.txt
 for k in ff tconv lnlin linres; do
   PMC_SCRIPT=one_fused.py bash tools/pmc_one_gemm.sh $k $k > $O/pmc_$k.log 2>&1; python tools/pmc_summary.py $R/gpurun_out/pmc_$k > $O/${TAG}_pmc_$k.txt 2>&1; tail -8 $O/${TAG}_pmc_$k.txt
 done
+fi
