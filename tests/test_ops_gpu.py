@@ -216,10 +216,11 @@ def flash_mode(request):
 
 @pytest.mark.parametrize("flash_mode", FLASH_MODES, indirect=True)
 @pytest.mark.parametrize("B,heads,Lq,Lk", [(2, 2, 1024, 1024), (1, 3, 768, 256), (1, 1, 1000, 512), (1, 2, 512, 2304),
-                                           (2, 1, 1152, 1152), (1, 1, 530, 128 + 64)])
+                                           (2, 1, 1152, 1152), (1, 2, 768, 320), (1, 1, 640, 448), (1, 1, 530, 128 + 64)])
 def test_flash_attn_long_self(ops, flash_mode, B, heads, Lq, Lk):
     """Shapes that take the one-wave-per-SIMD software-pipelined kernel (flash_pipe.hip: Lq >= 512, Lk >= 256, Lk % 64 == 0)
-    and, last case, its boundary (Lk = 192 stays on the two-waves kernel). Ragged Lq exercises the clamped tail rows."""
+    and, last case, its boundary (Lk = 192 stays on the two-waves kernel). Ragged Lq exercises the clamped tail rows, Lk = 256 /
+    320 / 448 the shortest rings (4, 5 and 7 tiles: the loop runs Lk / 64 - 1 iterations around a 4-stage ring)."""
     Cc = heads * 64
     q = bf(rnd(B, Lq, Cc, seed=11)); k = bf(rnd(B, Lk, Cc, seed=12)); v = bf(rnd(B, Lk, Cc, seed=13))
     o = torch.zeros(B * Lq, Cc, dtype=torch.bfloat16, device=DEV)
