@@ -665,7 +665,11 @@ void norm_linear_kernel(const LlParams p) {
     const int fr = lane & 31, fh = lane >> 5;
     const unsigned lds_base = (unsigned)(unsigned long)((lds_char_t*)smem);
     char* const ebuf = smem + 2 * LW_STAGE + wave * 2048;
-    const int tile = (int)blockIdx.x / p.nsplit, part = (int)blockIdx.x - tile * p.nsplit;
+    // the nsplit workgroups of a row tile read the same activation rows: they are 8 block ids apart, i.e. on one XCD at about the
+    // same time, so that the second read is an L2 hit (consecutive ids go to different XCDs: counters showed X fetched nsplit times)
+    const int bgrp = (int)blockIdx.x / (8 * p.nsplit), brem = (int)blockIdx.x - bgrp * (8 * p.nsplit);
+    const int tile = bgrp * 8 + (brem & 7), part = brem >> 3;
+    if (tile * FBM >= p.M) return;                                   // padding blocks of the last group of 8 tiles
     const int m0 = tile * FBM + wave * 32;
     const bool full_tile = tile * FBM + FBM <= p.M;                    // ragged last tile: uncounted vmcnt waits
     const int c_begin = part * p.cpp;
@@ -1051,6 +1055,7 @@ struct TcParams {
     const float* gn_g; const float* gn_b; const float2* gn_stats; int gn_groups;      // stats [clip][group] = (mean, rstd)
     int HW, N;
     int nsplit, cpp;             // workgroups per row tile, chunks per workgroup (few row tiles: split N)
+    int ntiles;                  // row tiles (the grid is padded to groups of 8 tiles x nsplit)
 };
 
 // C = 320 KH input channels; the taps run in the order 1, 0, 2 so that only `out` and the current product are live
@@ -1068,7 +1073,9 @@ void gn_silu_tconv_kernel(const TcParams p) {
     float* const lns = reinterpret_cast<float*>(smem + 2 * LW_STAGE + 4 * 2048);
     float* const bls = lns + 2 * KD;                     // the bias in LDS (as in norm_linear_kernel)
     const bool bias_lds = KH == 1 && p.N <= LL_BIAS;     // (C = 640 sits at 256 registers: it keeps its loads in the epilogue)
-    const int tile = (int)blockIdx.x / p.nsplit, part = (int)blockIdx.x - tile * p.nsplit;
+    const int bgrp = (int)blockIdx.x / (8 * p.nsplit), brem = (int)blockIdx.x - bgrp * (8 * p.nsplit);
+    const int tile = bgrp * 8 + (brem & 7), part = brem >> 3;      // the parts of a tile on one XCD (see norm_linear_kernel)
+    if (tile >= p.ntiles) return;
     const int gpb = p.HW >> 3;
     const int b = tile / gpb, p0 = (tile - b * gpb) * 8 + 2 * wave;
     auto grow = [&](int r) { return ((size_t)(b * 16 + (r & 15))) * p.HW + p0 + (r >> 4); };      // wave row r -> tensor row
@@ -1304,7 +1311,7 @@ static int launch_norm_linear(int norm, int K, LlParams& p, hipStream_t stream) 
     while (tiles * nsplit < 3 * slots && nsplit * 2 <= nch && nch / (nsplit * 2) >= 5) nsplit *= 2;
     p.nsplit = nsplit;
     p.cpp = (nch + nsplit - 1) / nsplit;
-    const dim3 grid(tiles * nsplit);
+    const dim3 grid((tiles + 7) / 8 * 8 * nsplit);
     if (p.R) return K == FD ? launch_norm_linear_t<0, 1, true>(p, grid, stream) : launch_norm_linear_t<0, 2, true>(p, grid, stream);
     if (K == FD) {
         if (norm == 1) return launch_norm_linear_t<1, 1>(p, grid, stream);
@@ -1395,8 +1402,8 @@ extern "C" int dc_gn_silu_tconv3(const uint16_t* x, int ldx, int C, const float*
     const int tiles = B * (HW / 8), nch = N / LCH, slots = 256 * 2;
     int nsplit = 1;
     while (tiles * nsplit < 3 * slots && nsplit * 2 <= nch && nch / (nsplit * 2) >= 5) nsplit *= 2;
-    p.nsplit = nsplit; p.cpp = (nch + nsplit - 1) / nsplit;
-    const dim3 grid((unsigned)(tiles * nsplit));
+    p.nsplit = nsplit; p.cpp = (nch + nsplit - 1) / nsplit; p.ntiles = tiles;
+    const dim3 grid((unsigned)((tiles + 7) / 8 * 8 * nsplit));
     hipStream_t stream = (hipStream_t)stream_;
     if (C == FD) return residual ? launch_gn_silu_tconv<1, true>(p, grid, stream) : launch_gn_silu_tconv<1, false>(p, grid, stream);
     return residual ? launch_gn_silu_tconv<2, true>(p, grid, stream) : launch_gn_silu_tconv<2, false>(p, grid, stream);
