@@ -16,6 +16,8 @@
 #include "dcrafter_hip.h"
 #include <stdint.h>
 #include <stdlib.h>
+#include <type_traits>
+#include <utility>
 
 namespace {
 
@@ -589,6 +591,8 @@ __device__ __forceinline__ void persist_tile(int logical, int tiles_m, int tiles
     }
 }
 
+#include "gemm_pipe.h"
+
 template <int BN, bool GEGLU, int GSTAGES, int EPI, int MODE>
 __global__ __launch_bounds__(GNT) void gemm_persist_kernel(const DcGemmParams p, const int tile_group) {
     static_assert(MODE == 0 || !GEGLU, "GEGLU is a plain-GEMM epilogue");
@@ -939,6 +943,36 @@ int launch_glds(const DcGemmParams& p, hipStream_t stream) {
     return 0;
 }
 
+// The one-wave-per-SIMD 256 x 320 kernel (gemm_pipe.h) takes a launch when its addressing applies: bf16 output through the
+// row-major epilogue, whole 64-channel slices, activation offsets below 2^31. DC_GEMM_PIPE=0: the 8-wave kernels (A/B runs).
+inline bool pipe_ok(const DcGemmParams& p) {
+    // default: the 3x3 convs only (measured +0.5 .. +5 % there; plain / temporal shapes within noise of the 8-wave kernel);
+    // DC_GEMM_PIPE=2 also sends the other modes here, =0 none
+    static const int on = [] { const char* e = getenv("DC_GEMM_PIPE"); return e ? atoi(e) : 1; }();
+    if (on == 1 && p.mode != 1) return false;
+    if (!on || (p.flags & (DC_GEMM_GEGLU | DC_GEMM_OUT_F32)) || p.ups) return false;
+    if (p.N % 320 != 0 || p.n_pad < p.N || p.K % 64 != 0 || p.lda % 8 != 0 || ((uintptr_t)p.A % 16) != 0) return false;
+    if (p.ldc % 8 != 0 || ((uintptr_t)p.C % 16) != 0 || (long long)p.M * p.ldc >= (1ll << 31)) return false;
+    if (p.residual && (p.ldr % 8 != 0 || ((uintptr_t)p.residual % 16) != 0 || (long long)p.M * p.ldr >= (1ll << 31))) return false;
+    long long rows = p.M, extra = 0;
+    if (p.mode == 1) { if (p.Cin % 64 != 0 || p.K != 9 * p.Cin) return false; rows = (long long)(p.M / (p.OH * p.OW) + 1) * p.IH * p.IW; extra = 2ll * p.IW + 2; }
+    else if (p.mode == 2) { if (p.Cin % 64 != 0 || p.K != 3 * p.Cin) return false; extra = 2ll * p.HW; }
+    else if (p.mode != 0) return false;
+    if ((rows + extra) * p.lda * 2 >= (1ll << 31)) return false;
+    if (320ll * p.K * 2 >= (1ll << 31)) return false;
+    return true;
+}
+
+int launch_pipe_whole(const DcGemmParams& p, hipStream_t stream) {
+    const int ntiles = ((p.M + GBM - 1) / GBM) * (p.N / 320);
+    GemmSplit sp;
+    sp.partial = nullptr; sp.splits = 1; sp.tile_begin = 0; sp.tile_count = ntiles;
+    dc_note_variant(p.mode == 0 ? "gemm_pipe320_kernel" : p.mode == 2 ? "gemm_pipe320_kernel<tconv>" : "gemm_pipe320_kernel<conv>");
+    if (p.mode == 0) return p.residual ? launch_pipe320<0, 1>(p, stream, sp, ntiles, 1) : launch_pipe320<0, 0>(p, stream, sp, ntiles, 1);
+    if (p.mode == 1) return p.residual ? launch_pipe320<1, 1>(p, stream, sp, ntiles, 1) : launch_pipe320<1, 0>(p, stream, sp, ntiles, 1);
+    return p.residual ? launch_pipe320<2, 1>(p, stream, sp, ntiles, 1) : launch_pipe320<2, 0>(p, stream, sp, ntiles, 1);
+}
+
 // 320-wide tiles with split-K: `full` leading tiles as whole tiles (0 = none), the remaining tiles cut into `splits`
 // K ranges + reduce. Partials: splits * (ntiles - full) * 256 * 320 floats of workspace.
 template <int MODE>
@@ -947,6 +981,21 @@ int launch_glds320_split(const DcGemmParams& p, hipStream_t stream, int ntiles, 
     constexpr size_t lds = (size_t)GSTAGES * (GBM * GBK * 2 + BN * GBK * 2);
     static DcLdsOnce lds_once;
     if (const int e = lds_once.ensure(reinterpret_cast<const void*>(&gemm_conv_glds_kernel<BN, false, MODE, GSTAGES>), (int)lds)) return e;
+    if constexpr (MODE != 3) {
+        if (pipe_ok(p)) {
+            dc_note_variant(MODE == 0 ? "gemm_pipe320_kernel+splitk" : MODE == 2 ? "gemm_pipe320_kernel<tconv>+splitk" : "gemm_pipe320_kernel<conv>+splitk");
+            GemmSplit sp;
+            if (full > 0) {
+                sp.partial = nullptr; sp.splits = 1; sp.tile_begin = 0; sp.tile_count = full;
+                if (const int e = p.residual ? launch_pipe320<MODE, 1>(p, stream, sp, full, 1) : launch_pipe320<MODE, 0>(p, stream, sp, full, 1)) return e;
+            }
+            sp.partial = reinterpret_cast<float*>(p.workspace); sp.splits = splits; sp.tile_begin = full; sp.tile_count = ntiles - full;
+            if (const int e = launch_pipe320<MODE, 0>(p, stream, sp, sp.tile_count, splits)) return e;
+            hipLaunchKernelGGL((splitk_reduce_kernel<BN>), dim3((GBM * (BN / 4) + 255) / 256, sp.tile_count), dim3(256), 0, stream, p, sp);
+            DC_CHECK_LAUNCH();
+            return 0;
+        }
+    }
     dc_note_variant(MODE == 0 ? "gemm_conv_glds_kernel<320>+splitk" : MODE == 2 ? "gemm_conv_glds_kernel<320,tconv>+splitk" : "gemm_conv_glds_kernel<320,conv>+splitk");
     GemmSplit sp;
     if (full > 0) {
@@ -1062,13 +1111,13 @@ int dc_gemm_conv_glds_try(const DcGemmParams& p, hipStream_t stream) {
             return launch_glds320_split<2>(p, stream, w320, full, splits);
         }
     }
-    if (force == 320 && n320) return launch_glds_mode<320, 2>(p, stream);
+    if (force == 320 && n320) return pipe_ok(p) ? launch_pipe_whole(p, stream) : launch_glds_mode<320, 2>(p, stream);
     if (force == 128 && w128 > 0 && waste128 <= 1.15f) return launch_glds_mode<128, 3>(p, stream);
     if (force == 1) return -100;
     // 256-wide plain tile for the AutoencoderKL widths (N = 256 / 512: not multiples of 320)
     const int w256 = (!n320 && p.N % 256 == 0 && p.n_pad >= p.N) ? tiles_m * (p.N / 256) : 0;
     if ((force == 256 || force == 0) && w256 >= 200 && 1.2f * wave_eff(w256) >= s128) return launch_glds_mode<256, 2>(p, stream);
-    if (s320 > 0.f && s320 >= s128) return launch_glds_mode<320, 2>(p, stream);
+    if (s320 > 0.f && s320 >= s128) return pipe_ok(p) ? launch_pipe_whole(p, stream) : launch_glds_mode<320, 2>(p, stream);
     if (s128 > 0.f && waste128 <= 1.15f) return launch_glds_mode<128, 3>(p, stream);
     return -100;
 }
