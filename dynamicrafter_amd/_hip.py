@@ -50,6 +50,7 @@ SIGNATURES = {
     "dc_gemm_conv": (_I, [C.POINTER(DcGemmParams), _P]),
     "dc_gemm_workspace_bytes": (_L, []),
     "dc_gemm_last_variant": (C.c_char_p, []),
+    "dc_gemm_set_plan": (_I, [_I]),
     "dc_groupnorm": (_I, [_P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _F, _I, _P, _P]),
     "dc_groupnorm_workspace_bytes": (_L, [_I, _I, _I]),
     "dc_layernorm": (_I, [_P, _I, _P, _I, _P, _P, _I, _I, _F, _P]),

@@ -592,6 +592,7 @@ __device__ __forceinline__ void persist_tile(int logical, int tiles_m, int tiles
 }
 
 #include "gemm_pipe.h"
+#include "conv_pipe.h"
 
 template <int BN, bool GEGLU, int GSTAGES, int EPI, int MODE>
 __global__ __launch_bounds__(GNT) void gemm_persist_kernel(const DcGemmParams p, const int tile_group) {
@@ -943,14 +944,14 @@ int launch_glds(const DcGemmParams& p, hipStream_t stream) {
     return 0;
 }
 
-// The one-wave-per-SIMD 256 x 320 kernel (gemm_pipe.h) takes a launch when its addressing applies: bf16 output through the
-// row-major epilogue, whole 64-channel slices, activation offsets below 2^31. DC_GEMM_PIPE=0: the 8-wave kernels (A/B runs).
+// The one-wave-per-SIMD 256 x 320 kernel (gemm_pipe.h) takes a launch when dc_gemm_set_plan selects it and its addressing
+// applies: bf16 output through the row-major epilogue, whole 64-channel slices, activation offsets below 2^31.
+std::atomic<int> g_gemm_plan{[] { const char* e = getenv("DC_GEMM_PLAN"); return e ? atoi(e) : 0; }()};
+
 inline bool pipe_ok(const DcGemmParams& p) {
-    // default: the 3x3 convs only (measured +0.5 .. +5 % there; plain / temporal shapes within noise of the 8-wave kernel);
-    // DC_GEMM_PIPE=2 also sends the other modes here, =0 none
-    static const int on = [] { const char* e = getenv("DC_GEMM_PIPE"); return e ? atoi(e) : 1; }();
-    if (on == 1 && p.mode != 1) return false;
-    if (!on || (p.flags & (DC_GEMM_GEGLU | DC_GEMM_OUT_F32)) || p.ups) return false;
+    const int plan = g_gemm_plan.load(std::memory_order_relaxed);
+    if (!(plan & 3) || (!(plan & 2) && p.mode != 1)) return false;
+    if ((p.flags & (DC_GEMM_GEGLU | DC_GEMM_OUT_F32)) || p.ups) return false;
     if (p.N % 320 != 0 || p.n_pad < p.N || p.K % 64 != 0 || p.lda % 8 != 0 || ((uintptr_t)p.A % 16) != 0) return false;
     if (p.ldc % 8 != 0 || ((uintptr_t)p.C % 16) != 0 || (long long)p.M * p.ldc >= (1ll << 31)) return false;
     if (p.residual && (p.ldr % 8 != 0 || ((uintptr_t)p.residual % 16) != 0 || (long long)p.M * p.ldr >= (1ll << 31))) return false;
@@ -963,7 +964,27 @@ inline bool pipe_ok(const DcGemmParams& p) {
     return true;
 }
 
+// conv_pipe.h: stride-1 3x3 convs with the activation window in LDS (plan bit 2)
+inline bool conv_pipe_ok(const DcGemmParams& p) {
+    if (!(g_gemm_plan.load(std::memory_order_relaxed) & 4) || p.mode != 1 || p.ups || p.stride != 1 || p.pad != 1 || p.OH != p.IH || p.OW != p.IW || p.IW > 135) return false;
+    if (p.flags & (DC_GEMM_GEGLU | DC_GEMM_OUT_F32)) return false;
+    if (p.Cin % 64 != 0 || p.K != 9 * p.Cin || p.N % 320 != 0 || p.n_pad < p.N || p.lda % 8 != 0 || ((uintptr_t)p.A % 16) != 0) return false;
+    if (p.ldc % 8 != 0 || ((uintptr_t)p.C % 16) != 0 || (long long)p.M * p.ldc >= (1ll << 31)) return false;
+    if (p.residual && (p.ldr % 8 != 0 || ((uintptr_t)p.residual % 16) != 0 || (long long)p.M * p.ldr >= (1ll << 31))) return false;
+    if ((long long)p.M * p.lda * 2 >= (1ll << 32) || 320ll * p.K * 2 >= (1ll << 32)) return false;
+    return true;
+}
+
+int launch_conv_pipe_whole(const DcGemmParams& p, hipStream_t stream) {
+    const int ntiles = ((p.M + GBM - 1) / GBM) * (p.N / 320);
+    GemmSplit sp;
+    sp.partial = nullptr; sp.splits = 1; sp.tile_begin = 0; sp.tile_count = ntiles;
+    dc_note_variant("conv3_pipe320_kernel");
+    return p.residual ? launch_conv_pipe<1>(p, stream, sp, ntiles, 1) : launch_conv_pipe<0>(p, stream, sp, ntiles, 1);
+}
+
 int launch_pipe_whole(const DcGemmParams& p, hipStream_t stream) {
+    if (conv_pipe_ok(p)) return launch_conv_pipe_whole(p, stream);
     const int ntiles = ((p.M + GBM - 1) / GBM) * (p.N / 320);
     GemmSplit sp;
     sp.partial = nullptr; sp.splits = 1; sp.tile_begin = 0; sp.tile_count = ntiles;
@@ -981,6 +1002,21 @@ int launch_glds320_split(const DcGemmParams& p, hipStream_t stream, int ntiles, 
     constexpr size_t lds = (size_t)GSTAGES * (GBM * GBK * 2 + BN * GBK * 2);
     static DcLdsOnce lds_once;
     if (const int e = lds_once.ensure(reinterpret_cast<const void*>(&gemm_conv_glds_kernel<BN, false, MODE, GSTAGES>), (int)lds)) return e;
+    if constexpr (MODE == 1) {
+        if (conv_pipe_ok(p) && p.Cin / 32 >= splits) {
+            dc_note_variant("conv3_pipe320_kernel+splitk");
+            GemmSplit sp;
+            if (full > 0) {
+                sp.partial = nullptr; sp.splits = 1; sp.tile_begin = 0; sp.tile_count = full;
+                if (const int e = p.residual ? launch_conv_pipe<1>(p, stream, sp, full, 1) : launch_conv_pipe<0>(p, stream, sp, full, 1)) return e;
+            }
+            sp.partial = reinterpret_cast<float*>(p.workspace); sp.splits = splits; sp.tile_begin = full; sp.tile_count = ntiles - full;
+            if (const int e = launch_conv_pipe<0>(p, stream, sp, sp.tile_count, splits)) return e;
+            hipLaunchKernelGGL((splitk_reduce_kernel<BN>), dim3((GBM * (BN / 4) + 255) / 256, sp.tile_count), dim3(256), 0, stream, p, sp);
+            DC_CHECK_LAUNCH();
+            return 0;
+        }
+    }
     if constexpr (MODE != 3) {
         if (pipe_ok(p)) {
             dc_note_variant(MODE == 0 ? "gemm_pipe320_kernel+splitk" : MODE == 2 ? "gemm_pipe320_kernel<tconv>+splitk" : "gemm_pipe320_kernel<conv>+splitk");
@@ -1111,13 +1147,18 @@ int dc_gemm_conv_glds_try(const DcGemmParams& p, hipStream_t stream) {
             return launch_glds320_split<2>(p, stream, w320, full, splits);
         }
     }
-    if (force == 320 && n320) return pipe_ok(p) ? launch_pipe_whole(p, stream) : launch_glds_mode<320, 2>(p, stream);
+    if (force == 320 && n320) return (pipe_ok(p) || conv_pipe_ok(p)) ? launch_pipe_whole(p, stream) : launch_glds_mode<320, 2>(p, stream);
     if (force == 128 && w128 > 0 && waste128 <= 1.15f) return launch_glds_mode<128, 3>(p, stream);
     if (force == 1) return -100;
     // 256-wide plain tile for the AutoencoderKL widths (N = 256 / 512: not multiples of 320)
     const int w256 = (!n320 && p.N % 256 == 0 && p.n_pad >= p.N) ? tiles_m * (p.N / 256) : 0;
     if ((force == 256 || force == 0) && w256 >= 200 && 1.2f * wave_eff(w256) >= s128) return launch_glds_mode<256, 2>(p, stream);
-    if (s320 > 0.f && s320 >= s128) return pipe_ok(p) ? launch_pipe_whole(p, stream) : launch_glds_mode<320, 2>(p, stream);
+    if (s320 > 0.f && s320 >= s128) return (pipe_ok(p) || conv_pipe_ok(p)) ? launch_pipe_whole(p, stream) : launch_glds_mode<320, 2>(p, stream);
     if (s128 > 0.f && waste128 <= 1.15f) return launch_glds_mode<128, 3>(p, stream);
     return -100;
+}
+
+extern "C" int dc_gemm_set_plan(int plan) {
+    if (plan < 0 || plan > 7) return DC_ERR_ARG;
+    return g_gemm_plan.exchange(plan, std::memory_order_relaxed);
 }

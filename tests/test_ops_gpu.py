@@ -642,6 +642,74 @@ def test_tconv3_persistent(ops, B, T, HW):
     assert rel_l2(out, want) < 4e-3
 
 
+# ---- the one-wave-per-SIMD 320-wide kernels (gemm_pipe.h, conv_pipe.h) behind dc_gemm_set_plan: same shapes, same checkers
+@pytest.fixture
+def gemm_plan(ops, request):
+    lib = ops._hip.lib()
+    prev = lib.dc_gemm_set_plan(request.param)
+    assert prev >= 0
+    yield request.param
+    lib.dc_gemm_set_plan(prev)
+
+
+def _variant(ops):
+    return ops._hip.lib().dc_gemm_last_variant().decode()
+
+
+PIPE_CONVS = [
+    (dict(n=8, C=1280, Co=1280, H=18, W=32, stride=1, pad=1, ups=0), True),       # 72 tiles: every tile cut 3 ways along K
+    (dict(n=32, C=640, Co=1280, H=18, W=32, stride=1, pad=1, ups=0), False),      # 288 tiles: 256 whole + 32 x 8 splits
+    (dict(n=32, C=320, Co=640, H=36, W=64, stride=1, pad=1, ups=0), True),        # 576 tiles: 512 whole + 64 x 4
+    (dict(n=30, C=192, Co=320, H=17, W=23, stride=1, pad=1, ups=0), False),       # ragged rows, odd image width, 3 slices
+    (dict(n=3, C=64, Co=320, H=130, W=135, stride=1, pad=1, ups=0), True),        # the widest window the LDS layout holds
+    (dict(n=36, C=128, Co=320, H=33, W=47, stride=1, pad=1, ups=0), False),
+]
+
+
+@pytest.mark.parametrize("gemm_plan", [1, 4], indirect=True)
+@pytest.mark.parametrize("cfg,res", PIPE_CONVS)
+def test_conv3x3_pipe_plans(ops, gemm_plan, cfg, res):
+    n, C, Co, H, W = (cfg[k] for k in ("n", "C", "Co", "H", "W"))
+    g = torch.Generator(device=DEV).manual_seed(7)
+    x = torch.randn(n, C, H, W, device=DEV, generator=g).to(torch.bfloat16)
+    w = torch.randn(Co, C, 3, 3, device=DEV, generator=g) * (9 * C) ** -0.5
+    b = torch.randn(Co, device=DEV, generator=g)
+    emb = torch.randn(n, Co, device=DEV, generator=g)                 # one vector per image (ResBlock emb_layers)
+    r = torch.randn(n * H * W, Co, device=DEV, generator=g).to(torch.bfloat16) if res else None
+    ref = F.conv2d(x.float(), w.to(torch.bfloat16).float(), b, padding=1).permute(0, 2, 3, 1).reshape(-1, Co)
+    ref = ref + emb.repeat_interleave(H * W, 0)
+    if res:
+        ref = ref.to(torch.bfloat16).float() + r.float()
+    pw = ops.PackedWeight.conv3x3(w.cpu(), b.cpu(), DEV)
+    rows = x.permute(0, 2, 3, 1).reshape(-1, C).contiguous()
+    outs = []
+    for _ in range(2):
+        out = torch.empty(n * H * W, Co, dtype=torch.bfloat16, device=DEV)
+        ops.gemm(rows, pw, out, conv=dict(IH=H, IW=W, OH=H, OW=W, stride=1, pad=1, ups=0), residual=r, rowvec=emb, rows_per_vec=H * W)
+        outs.append(out)
+    want = "conv3_pipe320" if gemm_plan == 4 else "gemm_pipe320"
+    assert want in _variant(ops), _variant(ops)
+    assert rel_l2(outs[0], ref) < 4e-3
+    assert torch.equal(outs[0], outs[1])                             # fixed summation order: bitwise reproducible
+
+
+@pytest.mark.parametrize("gemm_plan", [3], indirect=True)
+def test_gemm_and_tconv_pipe_plan(ops, gemm_plan):
+    # plain rows (K = 2560, split-K plan of 72 tiles) and the temporal 3-tap mode of the same kernel
+    test_gemm_plain_large(ops, 4608 + 33, 1280, 2560)
+    assert "gemm_pipe320" in _variant(ops) or "gemm_persist" in _variant(ops) or "glds" in _variant(ops)
+    M, N, K = 18432, 1280, 5120
+    x = bf(rnd(M, K, seed=1)); w = rnd(N, K, seed=2, scale=K ** -0.5); b = rnd(N, seed=3)
+    pw = ops.PackedWeight.linear(w, b, DEV)
+    out = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+    ops.gemm(x.to(DEV), pw, out)
+    assert "gemm_pipe320" in _variant(ops), _variant(ops)
+    assert rel_l2(out, x.float() @ bf(w).float().t() + b) < 4e-3
+    test_tconv3_splitk(ops)
+    assert "gemm_pipe320" in _variant(ops), _variant(ops)
+    test_tconv3_ragged_wide(ops)
+
+
 # ---- dispatch fuzz: random shapes across the tile / persistent / split-K decision boundaries. The checker is a
 # device-side fp32 matmul / conv (rocBLAS / MIOpen via torch) - CPU references of these sizes would take minutes.
 def _fuzz_cases():

@@ -45,6 +45,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--only", default="", help="substring filter on the shape names")
+    ap.add_argument("--data", default="randn", choices=["randn", "zeros", "ones", "small"],
+                    help="operand values: the chip is power-limited under MFMA load and the clock it holds depends on how many bits toggle")
     args = ap.parse_args()
     for name, kind, m, ci, co in SHAPES:
         if args.only and not any(o in name for o in args.only.split(",")):
@@ -72,6 +74,14 @@ def main():
             out = torch.empty(M, co, dtype=torch.bfloat16, device=DEV)
             kw = dict(tconv=dict(T=16, HW=H * W))
             flops = 2.0 * M * co * ci * 3
+        if args.data != "randn":
+            # same kernels, same addresses, other VALUES (results are not checked here)
+            fill = {"zeros": 0.0, "ones": 1.0, "small": 1.0}[args.data]
+            x.fill_(fill)
+            if args.data == "small":
+                x.copy_((torch.randint(0, 2, x.shape, device=DEV) * 2 - 1).to(torch.bfloat16))     # +-1: sign bit only
+            if args.data == "zeros":
+                pw.w.zero_()
         for _ in range(3):
             ops.gemm(x, pw, out, **kw)
         torch.cuda.synchronize()

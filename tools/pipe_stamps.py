@@ -1,4 +1,4 @@
-"""Where does a wave of gemm_pipe320_kernel wait? Builds an instrumented copy of the library (-DGP_STAMPS: shader clocks at the
+"""Where does a wave of gemm_pipe320_kernel / conv3_pipe320_kernel wait, and what clock does the chip hold under it? Builds an instrumented copy of the library (-DGP_STAMPS: shader clocks at the
 four waiting points of the tile loop), runs ONE conv / linear shape as whole tiles and prints per-K-tile averages.
 usage (GPU box): python tools/pipe_stamps.py conv|lin|tconv ci co H W      (STAMPS_EXTRA: more -D flags, e.g. -DGP_DBG_NOA)"""
 import os, subprocess, sys
@@ -12,6 +12,7 @@ os.environ["DC_HIP_LIB"] = lib
 os.environ["DC_GEMM_SPLITK"] = "0"
 os.environ["DC_GEMM_PERSIST"] = "0"
 os.environ["DC_GEMM_TILE"] = "320"
+os.environ.setdefault("DC_GEMM_PLAN", "1")       # 1: gemm_pipe.h, 5: conv_pipe.h for the stride-1 3x3 convs
 sys.path.insert(0, ROOT)
 import torch
 from dynamicrafter_amd import ops
