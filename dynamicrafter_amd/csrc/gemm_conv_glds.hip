@@ -592,6 +592,7 @@ __device__ __forceinline__ void persist_tile(int logical, int tiles_m, int tiles
 }
 
 #include "gemm_pipe.h"
+#include "gemm_pipe16.h"
 #include "conv_pipe.h"
 
 template <int BN, bool GEGLU, int GSTAGES, int EPI, int MODE>
@@ -946,11 +947,23 @@ int launch_glds(const DcGemmParams& p, hipStream_t stream) {
 
 // The one-wave-per-SIMD 256 x 320 kernel (gemm_pipe.h) takes a launch when dc_gemm_set_plan selects it and its addressing
 // applies: bf16 output through the row-major epilogue, whole 64-channel slices, activation offsets below 2^31.
-std::atomic<int> g_gemm_plan{[] { const char* e = getenv("DC_GEMM_PLAN"); return e ? atoi(e) : 0; }()};
+// default 11: the one-wave-per-SIMD kernel on v_mfma_f32_16x16x32_bf16 for every 3x3 conv and for the long-K (>= 1920) plain
+// and temporal launches: 10-18 % faster than the 8-wave kernel there (tools/pipe_ab.sh: the chip holds a higher clock on that
+// MFMA shape); short-K launches stay on the persistent kernels
+std::atomic<int> g_gemm_plan{[] { const char* e = getenv("DC_GEMM_PLAN"); return e ? atoi(e) : 11; }()};
+constexpr int PIPE_MIN_K = 1920;
+
+// plan bit 3: the one-wave-per-SIMD kernel on v_mfma_f32_16x16x32_bf16 (gemm_pipe16.h) instead of 32x32x16
+template <int MODE, int EPI>
+int launch_pipe_shape(const DcGemmParams& p, hipStream_t stream, const GemmSplit& sp, int gx, int gy) {
+    if (g_gemm_plan.load(std::memory_order_relaxed) & 8) return launch_pipe320x16<MODE, EPI>(p, stream, sp, gx, gy);
+    return launch_pipe320<MODE, EPI>(p, stream, sp, gx, gy);
+}
 
 inline bool pipe_ok(const DcGemmParams& p) {
     const int plan = g_gemm_plan.load(std::memory_order_relaxed);
     if (!(plan & 3) || (!(plan & 2) && p.mode != 1)) return false;
+    if (p.mode != 1 && p.K < PIPE_MIN_K) return false;
     if ((p.flags & (DC_GEMM_GEGLU | DC_GEMM_OUT_F32)) || p.ups) return false;
     if (p.N % 320 != 0 || p.n_pad < p.N || p.K % 64 != 0 || p.lda % 8 != 0 || ((uintptr_t)p.A % 16) != 0) return false;
     if (p.ldc % 8 != 0 || ((uintptr_t)p.C % 16) != 0 || (long long)p.M * p.ldc >= (1ll << 31)) return false;
@@ -988,10 +1001,13 @@ int launch_pipe_whole(const DcGemmParams& p, hipStream_t stream) {
     const int ntiles = ((p.M + GBM - 1) / GBM) * (p.N / 320);
     GemmSplit sp;
     sp.partial = nullptr; sp.splits = 1; sp.tile_begin = 0; sp.tile_count = ntiles;
-    dc_note_variant(p.mode == 0 ? "gemm_pipe320_kernel" : p.mode == 2 ? "gemm_pipe320_kernel<tconv>" : "gemm_pipe320_kernel<conv>");
-    if (p.mode == 0) return p.residual ? launch_pipe320<0, 1>(p, stream, sp, ntiles, 1) : launch_pipe320<0, 0>(p, stream, sp, ntiles, 1);
-    if (p.mode == 1) return p.residual ? launch_pipe320<1, 1>(p, stream, sp, ntiles, 1) : launch_pipe320<1, 0>(p, stream, sp, ntiles, 1);
-    return p.residual ? launch_pipe320<2, 1>(p, stream, sp, ntiles, 1) : launch_pipe320<2, 0>(p, stream, sp, ntiles, 1);
+    if (g_gemm_plan.load(std::memory_order_relaxed) & 8)
+        dc_note_variant(p.mode == 0 ? "gemm_pipe320x16_kernel" : p.mode == 2 ? "gemm_pipe320x16_kernel<tconv>" : "gemm_pipe320x16_kernel<conv>");
+    else
+        dc_note_variant(p.mode == 0 ? "gemm_pipe320_kernel" : p.mode == 2 ? "gemm_pipe320_kernel<tconv>" : "gemm_pipe320_kernel<conv>");
+    if (p.mode == 0) return p.residual ? launch_pipe_shape<0, 1>(p, stream, sp, ntiles, 1) : launch_pipe_shape<0, 0>(p, stream, sp, ntiles, 1);
+    if (p.mode == 1) return p.residual ? launch_pipe_shape<1, 1>(p, stream, sp, ntiles, 1) : launch_pipe_shape<1, 0>(p, stream, sp, ntiles, 1);
+    return p.residual ? launch_pipe_shape<2, 1>(p, stream, sp, ntiles, 1) : launch_pipe_shape<2, 0>(p, stream, sp, ntiles, 1);
 }
 
 // 320-wide tiles with split-K: `full` leading tiles as whole tiles (0 = none), the remaining tiles cut into `splits`
@@ -1019,14 +1035,17 @@ int launch_glds320_split(const DcGemmParams& p, hipStream_t stream, int ntiles, 
     }
     if constexpr (MODE != 3) {
         if (pipe_ok(p)) {
-            dc_note_variant(MODE == 0 ? "gemm_pipe320_kernel+splitk" : MODE == 2 ? "gemm_pipe320_kernel<tconv>+splitk" : "gemm_pipe320_kernel<conv>+splitk");
+            if (g_gemm_plan.load(std::memory_order_relaxed) & 8)
+                dc_note_variant(MODE == 0 ? "gemm_pipe320x16_kernel+splitk" : MODE == 2 ? "gemm_pipe320x16_kernel<tconv>+splitk" : "gemm_pipe320x16_kernel<conv>+splitk");
+            else
+                dc_note_variant(MODE == 0 ? "gemm_pipe320_kernel+splitk" : MODE == 2 ? "gemm_pipe320_kernel<tconv>+splitk" : "gemm_pipe320_kernel<conv>+splitk");
             GemmSplit sp;
             if (full > 0) {
                 sp.partial = nullptr; sp.splits = 1; sp.tile_begin = 0; sp.tile_count = full;
-                if (const int e = p.residual ? launch_pipe320<MODE, 1>(p, stream, sp, full, 1) : launch_pipe320<MODE, 0>(p, stream, sp, full, 1)) return e;
+                if (const int e = p.residual ? launch_pipe_shape<MODE, 1>(p, stream, sp, full, 1) : launch_pipe_shape<MODE, 0>(p, stream, sp, full, 1)) return e;
             }
             sp.partial = reinterpret_cast<float*>(p.workspace); sp.splits = splits; sp.tile_begin = full; sp.tile_count = ntiles - full;
-            if (const int e = launch_pipe320<MODE, 0>(p, stream, sp, sp.tile_count, splits)) return e;
+            if (const int e = launch_pipe_shape<MODE, 0>(p, stream, sp, sp.tile_count, splits)) return e;
             hipLaunchKernelGGL((splitk_reduce_kernel<BN>), dim3((GBM * (BN / 4) + 255) / 256, sp.tile_count), dim3(256), 0, stream, p, sp);
             DC_CHECK_LAUNCH();
             return 0;
@@ -1077,7 +1096,8 @@ int dc_gemm_conv_glds_try(const DcGemmParams& p, hipStream_t stream) {
     const bool epi16 = out_f32 || ((n_out % 8 == 0) && (p.ldc % 8 == 0) && ((long long)p.M * p.ldc < (1ll << 31)) &&
                                    ((long long)p.M * p.ldr < (1ll << 31)) && ((uintptr_t)p.C % 16 == 0) &&
                                    (!p.residual || ((p.ldr % 8 == 0) && ((uintptr_t)p.residual % 16 == 0))));
-    if (persist && force == 0 && p.mode == 0 && epi16 && p.K <= persist_max_k()) {
+    const bool prefer_pipe = (force == 0) && (pipe_ok(p) || conv_pipe_ok(p));
+    if (persist && force == 0 && p.mode == 0 && epi16 && p.K <= persist_max_k() && !prefer_pipe) {
         // one workgroup per CU; needs at least 2 output tiles per workgroup to have anything to overlap
         static const int wide = [] { const char* e = getenv("DC_GEMM_PERSIST_WIDE"); return e ? atoi(e) : 1; }();
         if (geglu) {
@@ -1098,7 +1118,7 @@ int dc_gemm_conv_glds_try(const DcGemmParams& p, hipStream_t stream) {
         }
     }
     static const int persist_conv_maxk = [] { const char* e = getenv("DC_GEMM_PERSIST_CONV_MAXK"); return e ? atoi(e) : 2880; }();
-    if (persist && force == 0 && !geglu && !out_f32 && epi16 && (p.mode == 2 || (p.mode == 1 && !p.ups)) &&
+    if (persist && force == 0 && !prefer_pipe && !geglu && !out_f32 && epi16 && (p.mode == 2 || (p.mode == 1 && !p.ups)) &&
         p.N % 320 == 0 && p.n_pad >= p.N && tiles_m * (p.N / 320) >= (p.mode == 1 ? 1024 : 512) && p.K <= persist_conv_maxk)
         return launch_persist_conv320(p, stream);      // (3x3 convs with 512..1023 tiles measured faster on the split-K plan:
                                                        //  [147456x320x2880] 684 vs 572 TF/s, [73728x640x2880] 890 vs 734)
@@ -1159,6 +1179,6 @@ int dc_gemm_conv_glds_try(const DcGemmParams& p, hipStream_t stream) {
 }
 
 extern "C" int dc_gemm_set_plan(int plan) {
-    if (plan < 0 || plan > 7) return DC_ERR_ARG;
+    if (plan < 0 || plan > 15) return DC_ERR_ARG;
     return g_gemm_plan.exchange(plan, std::memory_order_relaxed);
 }

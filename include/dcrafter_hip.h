@@ -58,12 +58,13 @@ typedef struct DcGemmParams {
  * stateless. */
 const char* dc_gemm_last_variant(void);
 
-/* Test / measurement hook: which kernels take the launches with 320-wide tiles. bit 0: the one-wave-per-SIMD kernel
- * (gemm_pipe.h: activations straight into registers, no barrier in the K loop) for the 3x3 convs, bit 1: for every mode,
- * bit 2: stride-1 3x3 convs with the activation window of a tile resident in LDS (conv_pipe.h: the nine taps of a channel
- * slice share one staging). Default 0 = the 8-wave LDS-DMA kernels: on MI355X all three run into the same power limit
- * (DESIGN 3.4), the plans exist to measure that. Process-wide (env DC_GEMM_PLAN sets the initial value). Returns the
- * previous plan, or DC_ERR_ARG. */
+/* Which kernels take the launches with 320-wide tiles. bit 0: the one-wave-per-SIMD kernel (gemm_pipe.h: activations straight
+ * into registers, no barrier in the K loop) for the 3x3 convs, bit 1: also for plain / temporal launches with K >= 1920, bit 3:
+ * that kernel on v_mfma_f32_16x16x32_bf16 instead of 32x32x16 (gemm_pipe16.h), bit 2: stride-1 3x3 convs with the activation
+ * window of a tile resident in LDS (conv_pipe.h: the nine taps of a channel slice share one staging). Default 11 (bits 0, 1, 3):
+ * the matrix pipe is power-managed on MI355X and holds a higher clock on the 16x16x32 shape. 0 = the 8-wave LDS-DMA
+ * kernels everywhere. All plans give the same results to bf16 rounding and each is bit-reproducible. Process-wide (env
+ * DC_GEMM_PLAN sets the initial value). Returns the previous plan, or DC_ERR_ARG. */
 int dc_gemm_set_plan(int plan);
 
 /* Recommended size of DcGemmParams.workspace (one buffer per stream; contents are scratch, no initialisation). */

@@ -666,7 +666,7 @@ PIPE_CONVS = [
 ]
 
 
-@pytest.mark.parametrize("gemm_plan", [1, 4], indirect=True)
+@pytest.mark.parametrize("gemm_plan", [1, 4, 9], indirect=True)
 @pytest.mark.parametrize("cfg,res", PIPE_CONVS)
 def test_conv3x3_pipe_plans(ops, gemm_plan, cfg, res):
     n, C, Co, H, W = (cfg[k] for k in ("n", "C", "Co", "H", "W"))
@@ -687,13 +687,13 @@ def test_conv3x3_pipe_plans(ops, gemm_plan, cfg, res):
         out = torch.empty(n * H * W, Co, dtype=torch.bfloat16, device=DEV)
         ops.gemm(rows, pw, out, conv=dict(IH=H, IW=W, OH=H, OW=W, stride=1, pad=1, ups=0), residual=r, rowvec=emb, rows_per_vec=H * W)
         outs.append(out)
-    want = "conv3_pipe320" if gemm_plan == 4 else "gemm_pipe320"
+    want = "conv3_pipe320" if gemm_plan == 4 else "gemm_pipe320x16" if gemm_plan == 9 else "gemm_pipe320_kernel"
     assert want in _variant(ops), _variant(ops)
     assert rel_l2(outs[0], ref) < 4e-3
     assert torch.equal(outs[0], outs[1])                             # fixed summation order: bitwise reproducible
 
 
-@pytest.mark.parametrize("gemm_plan", [3], indirect=True)
+@pytest.mark.parametrize("gemm_plan", [3, 11], indirect=True)
 def test_gemm_and_tconv_pipe_plan(ops, gemm_plan):
     # plain rows (K = 2560, split-K plan of 72 tiles) and the temporal 3-tap mode of the same kernel
     test_gemm_plain_large(ops, 4608 + 33, 1280, 2560)
