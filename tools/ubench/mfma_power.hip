@@ -59,8 +59,9 @@ __global__ __launch_bounds__(256) void mfma_loop(int iters, int mode, unsigned l
                 acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a[ia]), __builtin_bit_cast(bf16x8_t, b[ib]), acc[i], 0, 0, 0);
             } else {
                 // two 16x16x32 per 32x32x16 worth of flops, on accumulators of their own
-                acc4[2 * i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a[ia]), __builtin_bit_cast(bf16x8_t, b[ib]), acc4[2 * i], 0, 0, 0);
-                acc4[2 * i + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a[ia]), __builtin_bit_cast(bf16x8_t, b[(ib + 1) % NFRAG]), acc4[2 * i + 1], 0, 0, 0);
+                // (asm: with the builtin hipcc keeps these accumulators in the accumulator file and copies them per iteration)
+                asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc4[2 * i]) : "v"(a[ia]), "v"(b[ib]));
+                asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc4[2 * i + 1]) : "v"(a[ia]), "v"(b[(ib + 1) % NFRAG]));
             }
         }
         if (mode >= 3 && (it & 63) == 63) {        // keep the accumulators finite and their bits moving
