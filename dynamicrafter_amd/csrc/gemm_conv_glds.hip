@@ -956,15 +956,20 @@ constexpr int PIPE_MIN_K = 1920;
 // plan bit 3: the one-wave-per-SIMD kernel on v_mfma_f32_16x16x32_bf16 (gemm_pipe16.h) instead of 32x32x16
 template <int MODE, int EPI>
 int launch_pipe_shape(const DcGemmParams& p, hipStream_t stream, const GemmSplit& sp, int gx, int gy) {
-    if (g_gemm_plan.load(std::memory_order_relaxed) & 8) return launch_pipe320x16<MODE, EPI>(p, stream, sp, gx, gy);
-    return launch_pipe320<MODE, EPI>(p, stream, sp, gx, gy);
+    if constexpr (MODE == 3) {
+        return launch_pipe320x16<3, EPI>(p, stream, sp, gx, gy);           // (pipe_ok admits upsampling convs under plan bit 3 only)
+    } else {
+        if (g_gemm_plan.load(std::memory_order_relaxed) & 8) return launch_pipe320x16<MODE, EPI>(p, stream, sp, gx, gy);
+        return launch_pipe320<MODE, EPI>(p, stream, sp, gx, gy);
+    }
 }
 
 inline bool pipe_ok(const DcGemmParams& p) {
     const int plan = g_gemm_plan.load(std::memory_order_relaxed);
     if (!(plan & 3) || (!(plan & 2) && p.mode != 1)) return false;
     if (p.mode != 1 && p.K < PIPE_MIN_K) return false;
-    if ((p.flags & (DC_GEMM_GEGLU | DC_GEMM_OUT_F32)) || p.ups) return false;
+    if (p.flags & (DC_GEMM_GEGLU | DC_GEMM_OUT_F32)) return false;
+    if (p.ups && !((plan & 8) && p.mode == 1 && p.ups == 1 && p.stride == 1 && p.pad == 1 && p.OH == 2 * p.IH && p.OW == 2 * p.IW)) return false;
     if (p.N % 320 != 0 || p.n_pad < p.N || p.K % 64 != 0 || p.lda % 8 != 0 || ((uintptr_t)p.A % 16) != 0) return false;
     if (p.ldc % 8 != 0 || ((uintptr_t)p.C % 16) != 0 || (long long)p.M * p.ldc >= (1ll << 31)) return false;
     if (p.residual && (p.ldr % 8 != 0 || ((uintptr_t)p.residual % 16) != 0 || (long long)p.M * p.ldr >= (1ll << 31))) return false;
@@ -1002,10 +1007,12 @@ int launch_pipe_whole(const DcGemmParams& p, hipStream_t stream) {
     GemmSplit sp;
     sp.partial = nullptr; sp.splits = 1; sp.tile_begin = 0; sp.tile_count = ntiles;
     if (g_gemm_plan.load(std::memory_order_relaxed) & 8)
-        dc_note_variant(p.mode == 0 ? "gemm_pipe320x16_kernel" : p.mode == 2 ? "gemm_pipe320x16_kernel<tconv>" : "gemm_pipe320x16_kernel<conv>");
+        dc_note_variant(p.mode == 0 ? "gemm_pipe320x16_kernel" : p.mode == 2 ? "gemm_pipe320x16_kernel<tconv>"
+                        : p.ups ? "gemm_pipe320x16_kernel<conv,ups>" : "gemm_pipe320x16_kernel<conv>");
     else
         dc_note_variant(p.mode == 0 ? "gemm_pipe320_kernel" : p.mode == 2 ? "gemm_pipe320_kernel<tconv>" : "gemm_pipe320_kernel<conv>");
     if (p.mode == 0) return p.residual ? launch_pipe_shape<0, 1>(p, stream, sp, ntiles, 1) : launch_pipe_shape<0, 0>(p, stream, sp, ntiles, 1);
+    if (p.mode == 1 && p.ups) return p.residual ? launch_pipe_shape<3, 1>(p, stream, sp, ntiles, 1) : launch_pipe_shape<3, 0>(p, stream, sp, ntiles, 1);
     if (p.mode == 1) return p.residual ? launch_pipe_shape<1, 1>(p, stream, sp, ntiles, 1) : launch_pipe_shape<1, 0>(p, stream, sp, ntiles, 1);
     return p.residual ? launch_pipe_shape<2, 1>(p, stream, sp, ntiles, 1) : launch_pipe_shape<2, 0>(p, stream, sp, ntiles, 1);
 }
@@ -1033,10 +1040,11 @@ int launch_glds320_split(const DcGemmParams& p, hipStream_t stream, int ntiles, 
             return 0;
         }
     }
-    if constexpr (MODE != 3) {
+    {
         if (pipe_ok(p)) {
             if (g_gemm_plan.load(std::memory_order_relaxed) & 8)
-                dc_note_variant(MODE == 0 ? "gemm_pipe320x16_kernel+splitk" : MODE == 2 ? "gemm_pipe320x16_kernel<tconv>+splitk" : "gemm_pipe320x16_kernel<conv>+splitk");
+                dc_note_variant(MODE == 0 ? "gemm_pipe320x16_kernel+splitk" : MODE == 2 ? "gemm_pipe320x16_kernel<tconv>+splitk"
+                                : MODE == 3 ? "gemm_pipe320x16_kernel<conv,ups>+splitk" : "gemm_pipe320x16_kernel<conv>+splitk");
             else
                 dc_note_variant(MODE == 0 ? "gemm_pipe320_kernel+splitk" : MODE == 2 ? "gemm_pipe320_kernel<tconv>+splitk" : "gemm_pipe320_kernel<conv>+splitk");
             GemmSplit sp;

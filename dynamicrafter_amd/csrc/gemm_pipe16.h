@@ -1,4 +1,4 @@
-// gemm_pipe320_kernel (gemm_pipe.h) on v_mfma_f32_16x16x32_bf16: the same tiles, ring, counters and byte streams, the other
+// gemm_pipe320_kernel (gemm_pipe.h) on v_mfma_f32_16x16x32_bf16 (+ MODE 3: 3x3 conv behind a fused nearest x2 upsampling): the same tiles, ring, counters and byte streams, the other
 // bf16 MFMA shape. Why: under an MFMA stream the chip is power-managed and the clock it holds depends on the
 // shape - on random operands the 16x16x32 loop delivers more FLOP/s than the 32x32x16 loop at equal cycles per FLOP
 // (MI355X_MICROARCH.md 'DVFS give-back' item 7; tools/ubench/mfma_power). Same output tile per wave (64 rows x 320 columns):
@@ -61,6 +61,7 @@ void gemm_pipe320x16_kernel(const DcGemmParams p, const GemmSplit sp) {
     long long bias = 0;                                     // the descriptor's base lies `bias` bytes in front of p.A
     if (MODE == 1) bias = (long long)(p.pad * p.IW + p.pad) * lda2;
     if (MODE == 2) bias = (long long)p.HW * lda2;
+    if (MODE == 3) bias = (long long)(p.IW + 1) * lda2;
 #pragma unroll
     for (int rb = 0; rb < 4; ++rb) {
         const int m = m0 + wave * 64 + rb * 16 + lr;
@@ -84,6 +85,23 @@ void gemm_pipe320x16_kernel(const DcGemmParams p, const GemmSplit sp) {
             }
             mask[rb] = mk;
             rowoff[rb] = (unsigned)(((n * p.IH + iy0 + p.pad) * p.IW + ix0 + p.pad)) * lda2 + lq * 16;
+        } else if (MODE == 3) {
+            // nearest x2 upsampling fused into the conv (stride 1, pad 1): tap (dy, dx) of output pixel (oy, ox) reads input pixel
+            // ((oy + dy - 1) >> 1, (ox + dx - 1) >> 1) = centre (oy >> 1, ox >> 1) + (ry, rx), ry = {py - 1, 0, py}[dy] with py = oy & 1
+            // (rx likewise): the offset is the centre's (+ bias) and two per-lane selects by the parities (mask bits 9, 10)
+            const int ohw = p.OH * p.OW;
+            const int n = mm / ohw;
+            const int rem = mm - n * ohw;
+            const int oy = rem / p.OW;
+            const int ox = rem - oy * p.OW;
+            int mk = 0;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int uy = oy + t / 3 - 1, ux = ox + t % 3 - 1;
+                if (ok && uy >= 0 && uy < p.OH && ux >= 0 && ux < p.OW) mk |= 1 << t;
+            }
+            mask[rb] = mk | ((oy & 1) << 9) | ((ox & 1) << 10);
+            rowoff[rb] = (unsigned)(((n * p.IH + (oy >> 1) + 1) * p.IW + (ox >> 1) + 1)) * lda2 + lq * 16;
         } else {
             const int frame = (mm / p.HW) % p.T;
             int mk = 0;
@@ -113,6 +131,19 @@ void gemm_pipe320x16_kernel(const DcGemmParams p, const GemmSplit sp) {
             tap = kt - cs * 9;
             const int dy = tap / 3, dx = tap - dy * 3;
             soff = (dy * p.IW + dx) * (int)lda2 + cs * 128;
+        } else if (MODE == 3) {
+            const int cs = kt / 9;
+            tap = kt - cs * 9;
+            const int dy = tap / 3, dx = tap - dy * 3;
+            soff = cs * 128;
+            const int y0 = dy == 0 ? -p.IW * (int)lda2 : 0, y1 = dy == 2 ? p.IW * (int)lda2 : 0;      // by the row parity
+            const int x0 = dx == 0 ? -(int)lda2 : 0, x1 = dx == 2 ? (int)lda2 : 0;                    // by the column parity
+#pragma unroll
+            for (int rb = 0; rb < 4; ++rb) {
+                const unsigned o = rowoff[rb] + (unsigned)(((mask[rb] >> 9) & 1) ? y1 : y0) + (unsigned)(((mask[rb] >> 10) & 1) ? x1 : x0);
+                vo[rb] = ((mask[rb] >> tap) & 1) ? o : 0x80000000u;
+            }
+            return;
         } else {
             const int cs = kt / 3;
             tap = kt - cs * 3;
@@ -250,6 +281,10 @@ void gemm_pipe320x16_kernel(const DcGemmParams p, const GemmSplit sp) {
             else GP16_MFMA_V(acc_[rb][cb], Bf_[f % 5], A_[ST][rb][s]);
         });
     };
+#ifdef GP_STAMPS        // tool build (tools/pipe_stamps.py): clocks of the tile loop and the shader clock the chip holds under it
+    const unsigned long long st_loop0 = __builtin_readcyclecounter();
+    const unsigned long long st_real0 = __builtin_amdgcn_s_memrealtime();
+#endif
     for (int t = 0; t < nk; t += 3) {
         tile(gp_ic<0>{}, t);
         if (t + 1 >= nk) break;
@@ -259,6 +294,14 @@ void gemm_pipe320x16_kernel(const DcGemmParams p, const GemmSplit sp) {
     }
     wait_vmcnt<0>();
     gp16_settle(acc);
+#ifdef GP_STAMPS
+    if (lane == 0 && p.workspace && !sp.partial && (size_t)(blockIdx.x * 4 + wave + 1) * 64 <= (size_t)p.workspace_bytes) {
+        unsigned long long* out = reinterpret_cast<unsigned long long*>(p.workspace) + (size_t)(blockIdx.x * 4 + wave) * 8;
+        out[0] = 0; out[1] = 0; out[2] = 0; out[3] = 0;
+        out[4] = __builtin_readcyclecounter() - st_loop0; out[5] = (unsigned long long)nk;
+        out[6] = __builtin_amdgcn_s_memrealtime() - st_real0;
+    }
+#endif
 
     // ---- epilogue. A lane holds, of output row 16 rb + lr, the channels 16 cb + 4 lq .. + 3 of every column block.
     if (sp.partial) {

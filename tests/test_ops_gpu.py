@@ -693,6 +693,18 @@ def test_conv3x3_pipe_plans(ops, gemm_plan, cfg, res):
     assert torch.equal(outs[0], outs[1])                             # fixed summation order: bitwise reproducible
 
 
+@pytest.mark.parametrize("gemm_plan", [11, 0], indirect=True)
+@pytest.mark.parametrize("cfg", [
+    dict(n=32, C=1280, Co=1280, H=9, W=16, stride=1, pad=1, ups=1),          # level 3 -> 2 Upsample: 72 tiles, split-K
+    dict(n=32, C=640, Co=640, H=18, W=32, stride=1, pad=1, ups=1),           # 288 x 2 tiles
+    dict(n=15, C=64, Co=320, H=33, W=27, stride=1, pad=1, ups=1),            # odd sizes: every parity / border combination, ragged rows
+])
+def test_conv3x3_upsample_fused_pipe16(ops, gemm_plan, cfg):
+    test_conv3x3(ops, cfg)
+    if gemm_plan == 11:                        # (n = 15: 209 row tiles -> whole 320-wide tiles)
+        assert "gemm_pipe320x16_kernel<conv,ups>" in _variant(ops), _variant(ops)
+
+
 @pytest.mark.parametrize("gemm_plan", [3, 11], indirect=True)
 def test_gemm_and_tconv_pipe_plan(ops, gemm_plan):
     # plain rows (K = 2560, split-K plan of 72 tiles) and the temporal 3-tap mode of the same kernel
