@@ -29,6 +29,9 @@ fi
 if [ "$PART" = all ] || [ "$PART" = pmc ]; then
 # PMC counters (MFMA busy, wait / issue split, L1 pending stalls, L2 <-> memory requests) of single kernels
 PMC_SCRIPT=one_flash.py bash tools/pmc_one_gemm.sh flash 32 5 9216 9216 > $O/pmc_flash.log 2>&1; python tools/pmc_summary.py $R/gpurun_out/pmc_flash > $O/${TAG}_pmc_flash.txt 2>&1; tail -12 $O/${TAG}_pmc_flash.txt
+# the level-1 skip-connection conv [73728 x 640 x 17280] on the default plan (gemm_pipe320x16_kernel) and on the 8-wave kernels
+bash tools/pmc_one_gemm.sh conv16 conv 1920 640 36 64 > $O/pmc_conv16.log 2>&1; python tools/pmc_summary.py $R/gpurun_out/pmc_conv16 > $O/${TAG}_pmc_conv16.txt 2>&1; tail -12 $O/${TAG}_pmc_conv16.txt
+DC_GEMM_PLAN=0 bash tools/pmc_one_gemm.sh conv8w conv 1920 640 36 64 > $O/pmc_conv8w.log 2>&1; python tools/pmc_summary.py $R/gpurun_out/pmc_conv8w > $O/${TAG}_pmc_conv8w.txt 2>&1; tail -12 $O/${TAG}_pmc_conv8w.txt
 for k in ff tconv lnlin linres; do
   PMC_SCRIPT=one_fused.py bash tools/pmc_one_gemm.sh $k $k > $O/pmc_$k.log 2>&1; python tools/pmc_summary.py $R/gpurun_out/pmc_$k > $O/${TAG}_pmc_$k.txt 2>&1; tail -8 $O/${TAG}_pmc_$k.txt
 done
