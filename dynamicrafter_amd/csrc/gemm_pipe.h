@@ -44,6 +44,14 @@ typedef __attribute__((address_space(3))) int gp_lds_int_t;
 #define GP_ST_BEGIN() do { } while (0)
 #define GP_ST_END(i) do { } while (0)
 #endif
+// A wait on an LDS counter. Every wave posts every counter the same number of times, so a wait always ends; the bound (about
+// 10 ms, once per wave) only keeps a future bookkeeping mistake from hanging the GPU - the results are then wrong, loudly.
+#define GP_SPIN(cond, reread)                                              \
+    do {                                                                   \
+        int spins__ = 0;                                                   \
+        while (!gave_up && (cond)) { reread; if (++spins__ > 200000) gave_up = 1; } \
+    } while (0)
+
 template <int V> using gp_ic = std::integral_constant<int, V>;
 template <int... G, class F>
 __device__ __forceinline__ void gp_for(std::integer_sequence<int, G...>, F&& f) { (f(gp_ic<G>{}), ...); }
@@ -100,6 +108,7 @@ void gemm_pipe320_kernel(const DcGemmParams p, const GemmSplit sp) {
     gp_lds_int_t* const cnt_freed = cnt_landed + 1;
     if (tid < 2) cnt_landed[tid] = 0;
     __syncthreads();
+    int gave_up = 0;                                        // see GP_SPIN
 
     // ---- activation rows: lane (fr, fh) holds bytes [32 s + 16 fh, +16) of K tile slices of rows 32 mb + fr of its wave
     const unsigned lda2 = (unsigned)p.lda * 2u;
@@ -242,7 +251,7 @@ void gemm_pipe320_kernel(const DcGemmParams p, const GemmSplit sp) {
     if (lane == 0) __hip_atomic_fetch_add(cnt_landed, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     {
         int seen = *(volatile gp_lds_int_t*)cnt_landed;
-        while (__builtin_amdgcn_readfirstlane(seen) < 4) seen = *(volatile gp_lds_int_t*)cnt_landed;
+        GP_SPIN(__builtin_amdgcn_readfirstlane(seen) < 4, seen = *(volatile gp_lds_int_t*)cnt_landed);
         asm volatile("" ::: "memory");
     }
 #pragma unroll
@@ -290,7 +299,7 @@ void gemm_pipe320_kernel(const DcGemmParams p, const GemmSplit sp) {
                     // stage ST2 held tile t-1: every wave is past its last fragment of it
                     GP_ST_BEGIN();
 #ifndef GP_DBG_NOSYNC
-                    while (__builtin_amdgcn_readfirstlane(seen_f) < 4 * t) seen_f = *(volatile gp_lds_int_t*)cnt_freed;
+                    GP_SPIN(__builtin_amdgcn_readfirstlane(seen_f) < 4 * t, seen_f = *(volatile gp_lds_int_t*)cnt_freed);
 #endif
                     GP_ST_END(2);
                     asm volatile("" ::: "memory");
@@ -325,7 +334,7 @@ void gemm_pipe320_kernel(const DcGemmParams p, const GemmSplit sp) {
                     // all four shares of tile t+1 have landed (it is first read in the next gap)
                     GP_ST_BEGIN();
 #ifndef GP_DBG_NOSYNC
-                    while (t + 1 < nk && __builtin_amdgcn_readfirstlane(seen_l) < 4 * (t + 2)) seen_l = *(volatile gp_lds_int_t*)cnt_landed;
+                    GP_SPIN(t + 1 < nk && __builtin_amdgcn_readfirstlane(seen_l) < 4 * (t + 2), seen_l = *(volatile gp_lds_int_t*)cnt_landed);
 #endif
                     GP_ST_END(3);
                     asm volatile("" ::: "memory");

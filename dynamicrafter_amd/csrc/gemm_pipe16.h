@@ -53,6 +53,7 @@ void gemm_pipe320x16_kernel(const DcGemmParams p, const GemmSplit sp) {
     gp_lds_int_t* const cnt_freed = cnt_landed + 1;
     if (tid < 2) cnt_landed[tid] = 0;
     __syncthreads();
+    int gave_up = 0;                                        // see GP_SPIN
 
     // ---- activation rows: lane (lr, lq) holds bytes [64 s + 16 lq, +16) of the K tile's slice of rows 16 rb + lr of its wave
     const unsigned lda2 = (unsigned)p.lda * 2u;
@@ -212,7 +213,7 @@ void gemm_pipe320x16_kernel(const DcGemmParams p, const GemmSplit sp) {
     if (lane == 0) __hip_atomic_fetch_add(cnt_landed, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     {
         int seen = *(volatile gp_lds_int_t*)cnt_landed;
-        while (__builtin_amdgcn_readfirstlane(seen) < 4) seen = *(volatile gp_lds_int_t*)cnt_landed;
+        GP_SPIN(__builtin_amdgcn_readfirstlane(seen) < 4, seen = *(volatile gp_lds_int_t*)cnt_landed);
         asm volatile("" ::: "memory");
     }
 #pragma unroll
@@ -248,7 +249,7 @@ void gemm_pipe320x16_kernel(const DcGemmParams p, const GemmSplit sp) {
                 if constexpr (g == 2) seen_f = *(volatile gp_lds_int_t*)cnt_freed;
                 if constexpr (g == 6) {
                     // stage ST2 held tile t-1: every wave is past its last fragment of it
-                    while (__builtin_amdgcn_readfirstlane(seen_f) < 4 * t) seen_f = *(volatile gp_lds_int_t*)cnt_freed;
+                    GP_SPIN(__builtin_amdgcn_readfirstlane(seen_f) < 4 * t, seen_f = *(volatile gp_lds_int_t*)cnt_freed);
                     asm volatile("" ::: "memory");
                     ws = w_src(kt2);
                 }
@@ -269,7 +270,7 @@ void gemm_pipe320x16_kernel(const DcGemmParams p, const GemmSplit sp) {
                 if constexpr (g == 118) seen_l = *(volatile gp_lds_int_t*)cnt_landed;
                 if constexpr (g == 142) {
                     // all four shares of tile t+1 have landed (it is first read two gaps on)
-                    while (t + 1 < nk && __builtin_amdgcn_readfirstlane(seen_l) < 4 * (t + 2)) seen_l = *(volatile gp_lds_int_t*)cnt_landed;
+                    GP_SPIN(t + 1 < nk && __builtin_amdgcn_readfirstlane(seen_l) < 4 * (t + 2), seen_l = *(volatile gp_lds_int_t*)cnt_landed);
                     asm volatile("" ::: "memory");
                 }
                 if constexpr (g == 150) {
