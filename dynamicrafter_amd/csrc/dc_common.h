@@ -98,6 +98,12 @@ int dc_flash_pipe_launch(const bf16_t* q, const bf16_t* k, const bf16_t* v, bf16
                          int batch, int heads, int Lq, int Lk, int64_t q_bstride, int64_t kv_bstride, float c,
                          hipStream_t stream);
 
+// flash_pipe16.hip: the main pass of the long self-attention on v_mfma_f32_16x16x32_bf16 (Lq % 384 == 0); flags[workgroup] = 1
+// where the shift-0 softmax left its range (dc_flash_pipe_launch then runs the tracking pass for those)
+int dc_flash_x16_launch(const bf16_t* q, const bf16_t* k, const bf16_t* v, bf16_t* o, int ldq, int ldk, int ldv, int ldo,
+                        int batch, int heads, int Lq, int Lk, int64_t q_bstride, int64_t kv_bstride, float c, int* flags,
+                        hipStream_t stream);
+
 // hipFuncAttributeMaxDynamicSharedMemorySize is a PER-DEVICE attribute: kernels with more than 64 KB of dynamic LDS are
 // configured once per device (bit mask; two host threads racing on the first call both set the attribute, which is harmless).
 struct DcLdsOnce {

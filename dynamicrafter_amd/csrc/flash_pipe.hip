@@ -99,7 +99,7 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1)))
 void flash_attn_d64_pipe_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,
                                 bf16_t* __restrict__ o, int ldq, int ldk, int ldv, int ldo, int heads, int Lq, int Lk,
                                 int64_t q_bstride, int64_t kv_bstride, float c /* scale*log2(e) */, int q_tiles, float thr,
-                                int force_track) {
+                                int force_track, const int* __restrict__ only_flagged) {
     static_assert(QB == 2 || QB == 3, "query blocks per wave");
     constexpr int ROWS = 128 * QB;        // query rows per workgroup
     constexpr int NQK = 4 * QB;           // score MFMAs of a step (gaps 0 .. NQK-1)
@@ -112,6 +112,8 @@ void flash_attn_d64_pipe_kernel(const bf16_t* __restrict__ q, const bf16_t* __re
 
     const int nwg = gridDim.x;
     const int id = xcd_remap(blockIdx.x, nwg);
+    // second launch behind flash_attn_d64_x16_kernel (flash_pipe16.hip): only the workgroups whose flag it raised redo their rows
+    if (only_flagged && only_flagged[id] == 0) return;
     const int qt = id % q_tiles;
     const int bh = id / q_tiles;
     const int head = bh % heads;
@@ -545,13 +547,32 @@ extern "C" int dc_fp_debug_stamps(unsigned long long* out, int reset) {
 // running max before the state is rescaled (P <= 2^thr otherwise). Initial values from DC_FLASH_TRACK / DC_FLASH_QB2 /
 // DC_FLASH_THR.
 static int g_fp_mode = [] {
-    const char* t = getenv("DC_FLASH_TRACK"); const char* b = getenv("DC_FLASH_QB2");
-    return ((t && t[0] == '1') ? 1 : 0) | ((b && b[0] == '1') ? 2 : 0);
+    const char* t = getenv("DC_FLASH_TRACK"); const char* b = getenv("DC_FLASH_QB2"); const char* x = getenv("DC_FLASH_X16");
+    return ((t && t[0] == '1') ? 1 : 0) | ((b && b[0] == '1') ? 2 : 0) | ((x && x[0] == '1') ? 4 : 0);
 }();
 static float g_fp_thr = [] { const char* e = getenv("DC_FLASH_THR"); return e ? (float)atof(e) : 8.0f; }();
 extern "C" int dc_flash_attn_set_mode(int mode, float thr) {
-    if (mode < 0 || mode > 3 || !(thr >= 0.f) || thr > 64.f) return DC_ERR_ARG;
+    if (mode < 0 || mode > 7 || !(thr >= 0.f) || thr > 64.f) return DC_ERR_ARG;
     g_fp_mode = mode; g_fp_thr = thr;
+    return 0;
+}
+
+// One flag per workgroup of the 16x16x32 main pass, per device, allocated at the first use (outside any stream capture: the
+// first launch of a process is an eager one) and never freed
+constexpr long long FP_MAX_FLAGS = 1 << 20;
+static int fp_flag_buffer(int** out) {
+    static int* buf[64] = {};
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return (int)e;
+    if (dev < 0 || dev >= 64) return DC_ERR_ARG;
+    if (!buf[dev]) {
+        int* p = nullptr;
+        e = hipMalloc(&p, FP_MAX_FLAGS * sizeof(int));
+        if (e != hipSuccess) return (int)e;
+        buf[dev] = p;
+    }
+    *out = buf[dev];
     return 0;
 }
 
@@ -572,12 +593,23 @@ int dc_flash_pipe_launch(const bf16_t* q, const bf16_t* k, const bf16_t* v, bf16
     if (nwg > 0x7fffffffLL) return DC_ERR_SHAPE;
     // the byte offsets of the K / V buffer loads are 32-bit
     if ((long long)Lk * ldk * 2 >= 0x7fffffffLL || (long long)Lk * ldv * 2 >= 0x7fffffffLL) return DC_ERR_SHAPE;
+    // mode bit 2: the main pass on v_mfma_f32_16x16x32_bf16 (flash_pipe16.hip: no tracking pass of its own - it flags the
+    // workgroups whose row sums left the shift-0 range, and this kernel's tracking pass redoes exactly those); same 384-row tiling
+    if ((g_fp_mode & 4) && qb3 && !force_track && nwg <= FP_MAX_FLAGS) {
+        int* flags = nullptr;
+        if (const int e = fp_flag_buffer(&flags)) return e;
+        if (const int e = dc_flash_x16_launch(q, k, v, o, ldq, ldk, ldv, ldo, batch, heads, Lq, Lk, q_bstride, kv_bstride, c, flags, stream)) return e;
+        hipLaunchKernelGGL(flash_attn_d64_pipe_kernel<3>, dim3((unsigned)nwg), dim3(256), FP_LDS, stream, q, k, v, o, ldq, ldk, ldv,
+                           ldo, heads, Lq, Lk, q_bstride, kv_bstride, c, q_tiles, thr, 1, (const int*)flags);
+        DC_CHECK_LAUNCH();
+        return 0;
+    }
     if (qb3)
         hipLaunchKernelGGL(flash_attn_d64_pipe_kernel<3>, dim3((unsigned)nwg), dim3(256), FP_LDS, stream, q, k, v, o, ldq, ldk, ldv,
-                           ldo, heads, Lq, Lk, q_bstride, kv_bstride, c, q_tiles, thr, force_track);
+                           ldo, heads, Lq, Lk, q_bstride, kv_bstride, c, q_tiles, thr, force_track, (const int*)nullptr);
     else
         hipLaunchKernelGGL(flash_attn_d64_pipe_kernel<2>, dim3((unsigned)nwg), dim3(256), FP_LDS, stream, q, k, v, o, ldq, ldk, ldv,
-                           ldo, heads, Lq, Lk, q_bstride, kv_bstride, c, q_tiles, thr, force_track);
+                           ldo, heads, Lq, Lk, q_bstride, kv_bstride, c, q_tiles, thr, force_track, (const int*)nullptr);
     DC_CHECK_LAUNCH();
     return 0;
 }

@@ -1,0 +1,360 @@
+// flash_attn_d64_pipe_kernel's main pass (flash_pipe.hip) on v_mfma_f32_16x16x32_bf16.
+//
+// Why: inside the denoising step the long self-attention is the kernel the chip clocks lowest (1.79 GHz, profiles/
+// r03_clock_by_kernel.md) - it is power-bound - and the 16x16x32 shape holds a higher clock; per 32-key step of six
+// 16-row query blocks it also needs 54 MFMAs of 16 clocks (24 score + 24 output + 6 row-sum) where the 32x32x16 form needs 30 of
+// 32: the row sums cost half as much. What it gives up is issue room: 8 clocks per MFMA for one v_exp_f32, so the stream is
+// issue-bound by design (48 exp + 24 pack + ~20 memory instructions per 54 MFMAs).
+//
+//   S^T block (16 keys x 16 queries) = K_block (cQ)^T : A = K fragment (16 keys x 32 d), B = Q fragment (32 d x 16 queries),
+//       two MFMAs (d = 64); a lane holds, of its query (lane & 15), keys 4 (lane >> 4) .. + 3 of the block
+//   P^T operand of a 32-key step = the packed exponentials of the step's two score blocks: a lane's 8 k values are keys
+//       {4 q .. 4 q + 3} of block 0 and of block 1 (q = lane >> 4) - the V^T fragment is read in that key order
+//   O^T block (16 d x 16 queries) += V^T fragment (16 d x those 32 keys) P^T ; row sums: a ones fragment as A
+// Same ring (4 stages of 64 keys, registers -> LDS, arrival counter), same software pipeline (scores two steps ahead,
+// exponentials one step ahead) and the same shift-0 softmax as the 32x32x16 kernel. There is NO tracking pass here: a workgroup
+// whose row sums leave [2^-100, 2^100) raises its flag and the launcher's second launch - the 32x32x16 kernel in tracking mode,
+// restricted to flagged workgroups - redoes its rows.
+#include "dc_common.h"
+#include "dcrafter_hip.h"
+#include <type_traits>
+#include <utility>
+#include <stdlib.h>
+
+namespace {
+
+typedef __attribute__((address_space(3))) char lds_char_t;
+typedef __attribute__((address_space(3))) bf16x4_t lds_bf16x4_t;
+typedef const volatile __attribute__((address_space(3))) bf16x8_t lds_vfrag_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4v_t;
+
+constexpr int F16_VLD = 160;                 // bytes per V row in LDS: 8 consecutive keys on 8 distinct 32-byte bank groups
+constexpr int F16_KBYTES = 64 * 128;
+constexpr int F16_VBYTES = 64 * F16_VLD;
+constexpr int F16_STAGE = F16_KBYTES + F16_VBYTES;      // 18 KB
+constexpr int F16_RING = 4 * F16_STAGE;
+constexpr int F16_LDS = F16_RING + 64;
+constexpr int QB = 6;                        // 16-row query blocks per wave (96 rows; 384 per workgroup)
+
+template <int V> using ic = std::integral_constant<int, V>;
+template <int... G, class F>
+__device__ __forceinline__ void f16_for(std::integer_sequence<int, G...>, F&& f) { (f(ic<G>{}), ...); }
+
+#define F16_EXP(dst, src) asm volatile("v_exp_f32 %0, %1" : "=v"(dst) : "v"(src))
+#define F16_CVT(dst, lo, hi) asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(dst) : "v"(lo), "v"(hi))
+#define F16_MFMA_SZ(d, a, b) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=&v"(d) : "a"(a), "a"(b))
+#define F16_MFMA_S(d, a, b) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(d) : "a"(a), "a"(b))
+#define F16_MFMA_O(d, a, b) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(d) : "v"(a), "v"(b))
+#define F16_MFMA_L(d, a, b) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(d) : "a"(a), "v"(b))
+
+__device__ __forceinline__ void f16_settle(f32x4v_t (&O)[QB][4], f32x4v_t (&L)[QB]) {
+#pragma unroll
+    for (int x = 0; x < QB; ++x)
+        asm volatile("s_nop 7\n\ts_nop 7" : "+a"(O[x][0]), "+a"(O[x][1]), "+a"(O[x][2]), "+a"(O[x][3]), "+a"(L[x]));
+    asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");
+}
+
+__global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1)))
+void flash_attn_d64_x16_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,
+                               bf16_t* __restrict__ o, int ldq, int ldk, int ldv, int ldo, int heads, int Lq, int Lk,
+                               int64_t q_bstride, int64_t kv_bstride, float c /* scale*log2(e) */, int q_tiles, int* __restrict__ flags) {
+    constexpr int ROWS = 384;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lr = lane & 15, lq = lane >> 4;
+
+    const int nwg = gridDim.x;
+    const int id = xcd_remap(blockIdx.x, nwg);
+    const int qt = id % q_tiles;
+    const int bh = id / q_tiles;
+    const int head = bh % heads;
+    const int b = bh / heads;
+
+    const bf16_t* qb = q + (size_t)b * q_bstride * ldq + head * 64;
+    const bf16_t* kb = k + (size_t)b * kv_bstride * ldk + head * 64;
+    const bf16_t* vb = v + (size_t)b * kv_bstride * ldv + head * 64;
+    bf16_t* ob = o + (size_t)b * q_bstride * ldo + head * 64;
+
+    // ---- Q fragments (B operand: 32 d x 16 queries): lane (lr, lq) holds cQ[row][32 dk + 8 lq .. + 7]
+    int qrow[QB];
+    bf16x8_t Q[QB][2];
+#pragma unroll
+    for (int x = 0; x < QB; ++x) {
+        qrow[x] = qt * ROWS + (wave * QB + x) * 16 + lr;
+        const int qc = qrow[x] < Lq ? qrow[x] : Lq - 1;
+#pragma unroll
+        for (int dk = 0; dk < 2; ++dk) {
+            const u32x4_t raw = *reinterpret_cast<const u32x4_t*>(qb + (size_t)qc * ldq + dk * 32 + lq * 8);
+            u32x4_t sc;
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                sc[e] = pack_bf2(__uint_as_float(raw[e] << 16) * c, __uint_as_float(raw[e] & 0xffff0000u) * c);
+            Q[x][dk] = __builtin_bit_cast(bf16x8_t, sc);
+            asm volatile("" : "+a"(Q[x][dk]));
+        }
+    }
+
+    // ---- staging (as in flash_pipe.hip): 64 rows x 8 chunks of 16 B per tensor and tile, 2 rows per thread
+    const int chunk = tid & 7, srow = tid >> 3;
+    const int nt = Lk >> 6;
+    u32x4_t kreg[2], vreg[2];
+    const unsigned kgo = (unsigned)(srow * ldk + chunk * 8) * 2u, vgo = (unsigned)(srow * ldv + chunk * 8) * 2u;
+    const __amdgpu_buffer_rsrc_t krs = __builtin_amdgcn_make_buffer_rsrc((void*)kb, 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t vrs = __builtin_amdgcn_make_buffer_rsrc((void*)vb, 0, 0x7fffffff, 0x00020000);
+    auto load_piece = [&](int t, int j) __attribute__((always_inline)) {
+        t = t < nt ? t : nt - 1;
+        const int row0 = t * 64 + (j >> 1) * 32;
+        if (j & 1) vreg[j >> 1] = __builtin_amdgcn_raw_buffer_load_b128(vrs, vgo, row0 * 2 * ldv, 0);
+        else kreg[j >> 1] = __builtin_amdgcn_raw_buffer_load_b128(krs, kgo, row0 * 2 * ldk, 0);
+    };
+    const unsigned kso = (unsigned)(srow * 128 + ((chunk ^ ((srow >> 1) & 7)) << 4));
+    const unsigned vso = (unsigned)(F16_KBYTES + srow * F16_VLD + chunk * 16);
+    auto store_piece = [&](int stage, int j) __attribute__((always_inline)) {
+        char* sk = smem + stage * F16_STAGE;
+        if (j & 1) *reinterpret_cast<u32x4_t*>(sk + vso + (j >> 1) * 32 * F16_VLD) = vreg[j >> 1];
+        else *reinterpret_cast<u32x4_t*>(sk + kso + (j >> 1) * 4096) = kreg[j >> 1];
+    };
+
+    // ---- fragment addresses. K fragment (kb16, dk) of a 32-key step: rows 32 par + 16 kb16 + lr, chunk (4 dk + lq) ^ swizzle
+    int koff[2];
+#pragma unroll
+    for (int dk = 0; dk < 2; ++dk) koff[dk] = lr * 128 + (((4 * dk + lq) ^ ((lr >> 1) & 7)) << 4);
+    // V^T fragment (d block db): the 16-lane group lq supplies keys 4 lq + (li >> 2) of a 16-key block, d = 16 db + 4 (li & 3) ..
+    const int voff = F16_KBYTES + (4 * lq + (lr >> 2)) * F16_VLD + (lr & 3) * 8;
+    const unsigned lds0 = (unsigned)(uintptr_t)((const lds_char_t*)smem);
+
+    // ---- state
+    f32x4v_t S[2][2][QB];       // [step parity][16-key block][query block]
+    u32x4_t P[2][QB];           // [step parity][query block]: exp2(S) packed = B operand of the PV MFMAs
+    f32x4v_t O[QB][4];          // [query block][16-wide slice of d]
+    f32x4v_t L[QB];
+    bf16x8_t Kf[4];             // [2 kb16 + dk]
+    bf16x8_t Vf[4];
+    u32x4_t ONES = {0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
+    asm volatile("" : "+a"(ONES));
+
+    auto rd_k = [&](int slot, unsigned addr, int par) __attribute__((always_inline)) {      // slot = 2 kb16 + dk, addr = kx[dk]
+#ifdef F16_DBG_NOLDS            // tool builds (tools/flash_variants.sh x16_*): parts of the step off, results wrong, timing only
+        return;
+#endif
+        Kf[slot] = *(lds_vfrag_t*)((const lds_char_t*)(uintptr_t)addr + par * 4096 + (slot >> 1) * 2048);
+    };
+    bf16x4_t vlo;
+    auto rd_v_half = [&](int idx, unsigned addr, int par) __attribute__((always_inline)) {   // idx = 2 db + (0: block 0, 1: block 1)
+#ifdef F16_DBG_NOLDS
+        return;
+#endif
+        const int db = idx >> 1;
+        const lds_char_t* vp = (const lds_char_t*)(uintptr_t)addr + (par * 32) * F16_VLD + db * 32;
+        if (!(idx & 1)) {
+            vlo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_bf16x4_t*)(vp));
+        } else {
+            const bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_bf16x4_t*)(vp + 16 * F16_VLD));
+            bf16x8_t f;
+            f[0] = vlo[0]; f[1] = vlo[1]; f[2] = vlo[2]; f[3] = vlo[3];
+            f[4] = hi[0]; f[5] = hi[1]; f[6] = hi[2]; f[7] = hi[3];
+            Vf[db] = f;
+        }
+    };
+
+    __attribute__((address_space(3))) int* const ring_cnt = (__attribute__((address_space(3))) int*)(smem + F16_RING);
+    int seen = 0, gave_up = 0;
+    // One 32-key step (see flash_pipe.hip::step): QK of the step two ahead (gaps 0..23), exponentials of the step one ahead
+    // (gaps 0..47, packs four gaps behind), PV of this step (gaps 24..47), row sums (48..53); memory instructions: see the gap table below
+    auto step = [&](auto PAR_, auto QK_, auto EX_, auto PV_, auto NK_, auto NV_, auto RING_, const unsigned (&kn)[2], int knpar,
+                    unsigned vn, int vnpar, int tile, int stage) __attribute__((always_inline)) {
+        constexpr int PAR = decltype(PAR_)::value, RING = decltype(RING_)::value;
+        constexpr bool QK = decltype(QK_)::value, EX = decltype(EX_)::value, PV = decltype(PV_)::value;
+        constexpr bool NK = decltype(NK_)::value, NV = decltype(NV_)::value;
+        f32x4v_t (&Sw)[2][QB] = S[PAR];
+        f32x4v_t (&Sr)[2][QB] = S[PAR ^ 1];
+        u32x4_t (&Pr)[QB] = P[PAR];
+        u32x4_t (&Pw)[QB] = P[PAR ^ 1];
+        f32x4v_t (&O1)[QB][4] = O;
+        f32x4v_t (&L1)[QB] = L;
+        bf16x8_t (&Kf1)[4] = Kf;
+        bf16x8_t (&Vf1)[4] = Vf;
+        bf16x8_t (&Q1)[QB][2] = Q;
+        u32x4_t& ONES1 = ONES;
+        float pa[48];
+        f16_for(std::make_integer_sequence<int, 54>{}, [&](auto G_) __attribute__((always_inline)) {
+            constexpr int g = decltype(G_)::value;
+            f32x4v_t (&Sw_)[2][QB] = Sw;
+            f32x4v_t (&Sr_)[2][QB] = Sr;
+            u32x4_t (&Pr_)[QB] = Pr;
+            u32x4_t (&Pw_)[QB] = Pw;
+            f32x4v_t (&O_)[QB][4] = O1;
+            f32x4v_t (&L_)[QB] = L1;
+            bf16x8_t (&Kf_)[4] = Kf1;
+            bf16x8_t (&Vf_)[4] = Vf1;
+            bf16x8_t (&Q_)[QB][2] = Q1;
+            u32x4_t& ONES_ = ONES1;
+            float (&pa_)[48] = pa;
+            // ---- memory instructions, each in a gap of its own where its registers are free:
+            //   K fragments of the next step (Kf is last read in gap 23): gaps 24..27, behind the arrival check of odd steps;
+            //   V^T fragment db of the next step (Vf[db] is last read in gap 29 + 6 db): two transposed reads each;
+            //   ring (even steps): 4 LDS stores of tile T+2, 4 global loads of tile T+3, then the wave's arrival
+#ifndef F16_DBG_NOSTAGE
+            if constexpr (RING == 2) {
+                if constexpr (g == 18) seen = *(volatile __attribute__((address_space(3))) int*)ring_cnt;
+                if constexpr (g == 24) {
+                    int spins = 0;
+                    while (!gave_up && __builtin_amdgcn_readfirstlane(seen) < tile) {
+                        seen = *(volatile __attribute__((address_space(3))) int*)ring_cnt;
+                        if (++spins > 200000) gave_up = 1;
+                    }
+                    asm volatile("" ::: "memory");
+                }
+            }
+#endif
+            if constexpr (NK && g >= 24 && g <= 27) rd_k(g - 24, kn[(g - 24) & 1], knpar);
+            if constexpr (NV) {
+                constexpr int vg[8] = {31, 33, 37, 39, 43, 45, 49, 51};
+                f16_for(std::make_integer_sequence<int, 8>{}, [&](auto I_) __attribute__((always_inline)) {
+                    constexpr int i = decltype(I_)::value;
+                    if constexpr (vg[i] == g) rd_v_half(i, vn, vnpar);
+                });
+            }
+#ifndef F16_DBG_NOSTAGE
+            if constexpr (RING == 1) {
+                if constexpr (g == 28 || g == 30 || g == 32 || g == 34) store_piece(stage, (g - 28) / 2);
+                if constexpr (g == 36 || g == 38 || g == 40 || g == 42) load_piece(tile, (g - 36) / 2);
+                if constexpr (g == 44) {
+                    if (lane == 0) __hip_atomic_fetch_add(ring_cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+            }
+#endif
+            // ---- the matrix instruction
+            if constexpr (g < 24) {
+                if constexpr (QK) {
+                    constexpr int dk = g / 12, kb16 = (g % 12) / 6, x = g % 6;
+                    if constexpr (dk == 0) F16_MFMA_SZ(Sw_[kb16][x], Kf_[2 * kb16], Q_[x][0]);
+                    else F16_MFMA_S(Sw_[kb16][x], Kf_[2 * kb16 + 1], Q_[x][1]);
+                }
+            } else if constexpr (g < 48) {
+                if constexpr (PV) {
+                    constexpr int db = (g - 24) / 6, x = (g - 24) % 6;
+                    F16_MFMA_O(O_[x][db], Vf_[db], Pr_[x]);
+                }
+            } else {
+                if constexpr (PV) F16_MFMA_L(L_[g - 48], ONES_, Pr_[g - 48]);
+            }
+            // ---- vector work: one exponential per gap (0..47), the pack of a pair four gaps behind it (hipcc pads an s_nop
+            // between a v_exp_f32 and a consumer right behind it)
+#ifdef F16_DBG_NOEX
+            if constexpr (false) {
+#else
+            if constexpr (EX) {
+#endif
+                if constexpr (g < 48) {
+                    constexpr int x = g / 8, kb16 = (g % 8) / 4, e = g % 4;
+                    F16_EXP(pa_[g], Sr_[kb16][x][e]);
+                }
+                if constexpr (g >= 4 && g <= 50 && (g % 2) == 0) {
+                    constexpr int p0 = g - 4;                 // elements p0, p0 + 1
+                    unsigned w;
+                    F16_CVT(w, pa_[p0], pa_[p0 + 1]);
+                    Pw_[p0 / 8][(p0 % 8) / 2] = w;
+                }
+            }
+        });
+    };
+
+    // ---- one pass over all keys
+    using T_ = std::true_type;
+    using F_ = std::false_type;
+#pragma unroll
+    for (int x = 0; x < QB; ++x) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { O[x][0][r] = 0.f; O[x][1][r] = 0.f; O[x][2][r] = 0.f; O[x][3][r] = 0.f; L[x][r] = 0.f; }
+    }
+    {
+        u32x4_t kk0[2], vv0[2];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) load_piece(0, j);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) { kk0[i] = kreg[i]; vv0[i] = vreg[i]; }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) load_piece(1, j);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) store_piece(1, j);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) { kreg[i] = kk0[i]; vreg[i] = vv0[i]; }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) store_piece(0, j);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) load_piece(2, j);
+    }
+    if (tid == 0) *ring_cnt = 0;
+    __syncthreads();
+    unsigned ka[2], kb2[2], va, vb2;
+    auto set_addr = [&](unsigned (&kx)[2], unsigned& vx, int kst, int vst) __attribute__((always_inline)) {
+#pragma unroll
+        for (int dk = 0; dk < 2; ++dk) { kx[dk] = lds0 + kst * F16_STAGE + koff[dk]; asm volatile("" : "+v"(kx[dk])); }
+        vx = lds0 + vst * F16_STAGE + voff;
+        asm volatile("" : "+v"(vx));
+    };
+    set_addr(ka, va, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) rd_k(i, ka[i & 1], 0);
+    // h = -2: S(0); requests K(1)
+    step(ic<0>{}, T_{}, F_{}, F_{}, T_{}, F_{}, ic<0>{}, ka, 1, va, 0, 0, 0);
+    // h = -1: S(1), P(0); requests K(2) (tile 1) and V(0)
+    set_addr(kb2, vb2, 1, 0);
+    step(ic<1>{}, T_{}, T_{}, F_{}, T_{}, T_{}, ic<0>{}, kb2, 0, va, 0, 0, 0);
+    for (int T = 0; T < nt - 1; ++T) {
+        set_addr(ka, va, (T + 1) & 3, T & 3);
+        set_addr(kb2, vb2, (T + 2) & 3, (T + 1) & 3);
+        step(ic<0>{}, T_{}, T_{}, T_{}, T_{}, T_{}, ic<1>{}, ka, 1, va, 1, T + 3, (T + 2) & 3);
+        step(ic<1>{}, T_{}, T_{}, T_{}, T_{}, T_{}, ic<2>{}, kb2, 0, vb2, 0, 4 * (T + 1), 0);
+    }
+    set_addr(ka, va, 0, (nt - 1) & 3);
+    step(ic<0>{}, F_{}, T_{}, T_{}, F_{}, T_{}, ic<0>{}, ka, 0, va, 1, 0, 0);
+    step(ic<1>{}, F_{}, F_{}, T_{}, F_{}, F_{}, ic<0>{}, ka, 0, va, 0, 0, 0);
+    f16_settle(O, L);
+
+    // ---- row sums; a sum outside [2^-100, 2^100) (or NaN) flags the workgroup for the tracking pass of the 32x32x16 kernel
+    bool bad = gave_up != 0;
+    float inv[QB];
+#pragma unroll
+    for (int x = 0; x < QB; ++x) {
+        const float l = L[x][0];
+        bad |= !(l < 1.2676506e30f) || !(l > 7.8886091e-31f);
+        inv[x] = 1.0f / l;
+    }
+#if defined(F16_DBG_NOLDS) || defined(F16_DBG_NOSTAGE) || defined(F16_DBG_NOEX)
+    bad = false;
+#endif
+    const int any_bad = __syncthreads_or(bad ? 1 : 0);
+    if (tid == 0) flags[id] = any_bad;
+    // ---- epilogue: a lane holds, of its query row, d = 16 db + 4 lq .. + 3 (8-byte pieces)
+#pragma unroll
+    for (int x = 0; x < QB; ++x) {
+        if (qrow[x] >= Lq) continue;
+        bf16_t* orow = ob + (size_t)qrow[x] * ldo + 4 * lq;
+#pragma unroll
+        for (int db = 0; db < 4; ++db) {
+            uint2 pk;
+            pk.x = pack_bf2(O[x][db][0] * inv[x], O[x][db][1] * inv[x]);
+            pk.y = pack_bf2(O[x][db][2] * inv[x], O[x][db][3] * inv[x]);
+            *reinterpret_cast<uint2*>(orow + db * 16) = pk;
+        }
+    }
+}
+
+}  // namespace
+
+// Launcher: 0 = launched (flags[workgroup] = 1 where the shift-0 softmax left its range), > 0 hipError_t.
+int dc_flash_x16_launch(const bf16_t* q, const bf16_t* k, const bf16_t* v, bf16_t* o, int ldq, int ldk, int ldv, int ldo,
+                        int batch, int heads, int Lq, int Lk, int64_t q_bstride, int64_t kv_bstride, float c, int* flags,
+                        hipStream_t stream) {
+    static DcLdsOnce once;
+    if (const int e = once.ensure((const void*)flash_attn_d64_x16_kernel, F16_LDS)) return e;
+    const int q_tiles = Lq / 384;
+    const long long nwg = (long long)q_tiles * heads * batch;
+    hipLaunchKernelGGL(flash_attn_d64_x16_kernel, dim3((unsigned)nwg), dim3(256), F16_LDS, stream, q, k, v, o, ldq, ldk, ldv, ldo,
+                       heads, Lq, Lk, q_bstride, kv_bstride, c, q_tiles, flags);
+    DC_CHECK_LAUNCH();
+    return 0;
+}

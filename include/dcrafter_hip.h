@@ -107,7 +107,8 @@ int dc_flash_attn_d64(const uint16_t* q, const uint16_t* k, const uint16_t* v, u
 /* Test / measurement hook for the long self-attention path of dc_flash_attn_d64 (Lq >= 512, Lk >= 256, Lk % 64 == 0, no
  * accumulate: the one-wave-per-SIMD pipelined kernel, which runs softmax without a running maximum and repeats a workgroup's
  * block with a running-max pass when a row sum leaves [2^-100, 2^100)). mode bit 0: run the running-max pass directly; bit 1:
- * two 32-row query blocks per wave for every shape (default: three when Lq % 384 == 0); thr (0..64, exp2 units): how far a
+ * two 32-row query blocks per wave for every shape (default: three when Lq % 384 == 0); bit 2: the main pass on
+ * v_mfma_f32_16x16x32_bf16 (Lq % 384 == 0; a second launch runs the running-max pass for the workgroups it flags); thr (0..64, exp2 units): how far a
  * score must exceed the running max before that pass rescales its state. Process-wide; default mode 0, thr 8.
  * Returns 0 or DC_ERR_ARG. */
 int dc_flash_attn_set_mode(int mode, float thr);

@@ -202,7 +202,7 @@ def test_flash_attn_fused_qkv_and_spike(ops):
 # modes of the long self-attention kernel (dc_flash_attn_set_mode): (mode, thr) - default = no running max in the main pass (shift
 # 0, out-of-range row sums fall back to the tracking pass), three query blocks per wave when Lq % 384 == 0; bit 0 = the
 # running-max (tracking) pass run directly, with thr = 0 (rescale on every growth) and 8; bit 1 = two query blocks per wave
-FLASH_MODES = [(0, 8.0), (1, 0.0), (1, 8.0), (2, 8.0), (3, 0.0)]
+FLASH_MODES = [(0, 8.0), (1, 0.0), (1, 8.0), (2, 8.0), (3, 0.0), (4, 8.0)]      # 4: main pass on 16x16x32 (Lq % 384 == 0)
 
 
 @pytest.fixture
@@ -255,9 +255,10 @@ def test_flash_attn_long_self_running_max_jumps(ops, flash_mode, spikes, L):
     assert rel_l2(o, ref) < 6e-3
 
 
+@pytest.mark.parametrize("flash_mode", [(0, 8.0), (4, 8.0)], indirect=True)
 @pytest.mark.parametrize("L", [512, 768])
 @pytest.mark.parametrize("pos", [3, 33, 100, 300, 511])
-def test_flash_attn_long_self_fallback_to_tracking_pass(ops, pos, L):
+def test_flash_attn_long_self_fallback_to_tracking_pass(ops, flash_mode, pos, L):
     """A key whose scores reach +-600 in exp2 units: the default pass (no running max) overflows its row sums for most rows
     and the workgroup must repeat its block with the running-max pass (softmax is a one-hot on the spiked key for rows
     with a positive score, and the plain softmax elsewhere). A second launch with ordinary data follows: the fallback
@@ -283,7 +284,8 @@ def test_flash_attn_long_self_fallback_to_tracking_pass(ops, pos, L):
     assert rel_l2(o, ref) < 6e-3
 
 
-def test_flash_attn_long_self_all_scores_far_below_zero(ops):
+@pytest.mark.parametrize("flash_mode", [(0, 8.0), (4, 8.0)], indirect=True)
+def test_flash_attn_long_self_all_scores_far_below_zero(ops, flash_mode):
     """Every score of some rows below -100 in exp2 units (q and all keys anti-aligned and large): the default pass's row sums
     underflow there and the fallback must produce the ordinary softmax."""
     B, heads, L = 1, 1, 768

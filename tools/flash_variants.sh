@@ -10,7 +10,7 @@ FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -I$ROOT/include -I$CS"
 build() {  # name, extra flags
   /opt/rocm/bin/hipcc $FLAGS $2 -c "$CS/flash_pipe.hip" -o "$OUT/flash_pipe_$1.o"
   OBJS=""
-  for f in gemm_conv gemm_conv_glds ff_fused norms attention elementwise encoders runtime; do OBJS="$OBJS $CS/$f.o"; done
+  for f in gemm_conv gemm_conv_glds ff_fused norms attention flash_pipe16 elementwise encoders runtime; do OBJS="$OBJS $CS/$f.o"; done
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o "$OUT/libdc_$1.so" $OBJS "$OUT/flash_pipe_$1.o"
   rm -f "$OUT/flash_pipe_$1.o"
 }
@@ -35,6 +35,14 @@ for v in "$@"; do
     st_nostore) build st_nostore "-DFP_STAMPS -DFP_DBG_NOSTORE" ;;
     st_vinstep) build st_vinstep "-DFP_STAMPS -DFP_V_IN_STEP" ;;
     st_noex_nostage) build st_noex_nostage "-DFP_STAMPS -DFP_DBG_NOEX -DFP_DBG_NOSTAGE -DFP_DBG_NOBAR" ;;
+    x16_*) # tool builds of flash_pipe16.hip: x16_nolds, x16_nostage, x16_noex, x16_nolds_nostage, x16_mfma
+      fl=""; case "$v" in *nolds*) fl="$fl -DF16_DBG_NOLDS";; esac; case "$v" in *nostage*) fl="$fl -DF16_DBG_NOSTAGE";; esac
+      case "$v" in *noex*) fl="$fl -DF16_DBG_NOEX";; esac; case "$v" in *mfma*) fl="-DF16_DBG_NOLDS -DF16_DBG_NOSTAGE -DF16_DBG_NOEX";; esac
+      /opt/rocm/bin/hipcc $FLAGS $fl -c "$CS/flash_pipe16.hip" -o "$OUT/fp16_$v.o"
+      OBJS=""
+      for f in gemm_conv gemm_conv_glds ff_fused norms attention flash_pipe elementwise encoders runtime; do OBJS="$OBJS $CS/$f.o"; done
+      /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o "$OUT/libdc_$v.so" $OBJS "$OUT/fp16_$v.o"
+      rm -f "$OUT/fp16_$v.o" ;;
     *) echo "unknown variant $v"; exit 1 ;;
   esac
   echo "built $v"
