@@ -304,6 +304,11 @@ def main():
         per_rank = [dict(rank=i, step_ms=round(s[0].item(), 3), clip_seconds=round(s[1].item(), 3)) for i, s in enumerate(allst)]
         clip_s = max(s[2].item() for s in allst)                 # slowest rank's clip time bounds the job
     fps = world * T / clip_s
+    # a kernel whose bounded LDS-counter wait timed out has produced garbage: no line is printed for such a run (raises)
+    _hip.check_error_word("bench.py, after the timed steps and the AE")
+    # peak device memory of this rank: torch's allocator holds everything (weights, arena scratch, GEMM / GroupNorm workspaces,
+    # the pre-drawn noises); the reference README quotes 18.3 GB peak for 576x1024 (README.md:294)
+    peak_mem_gb = torch.cuda.max_memory_allocated(device) / 1e9
     guard = None
     if os.environ.get("DC_ARENA_GUARD", "0") == "1":
         # debugging aid: every scratch buffer sits between sentinel rows; raises if any launch wrote outside its buffer
@@ -316,6 +321,7 @@ def main():
         "value": round(fps, 4), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "bf16", "data": "synthetic (random-init weights, synthetic conditioning)",
+        "peak_mem_gb": round(peak_mem_gb, 2),
         "n_ranks_seen": dist.get_world_size() if world > 1 else 1, "backend": backend if world > 1 else None,
         "config": {"workload": f"inference_{res}_v1.0.yaml: 1 clip/GPU, 16 frames, latent {h}x{w}, DDIM 50 "
                                "uniform_trailing eta=1, CFG 7.5 batched (cond+uncond), guidance_rescale 0.7, "

@@ -97,6 +97,7 @@ SIGNATURES = {
     "dc_event_record": (_I, [_P, _P]),
     "dc_event_elapsed_ms": (_I, [_P, _P, C.POINTER(_F)]),
     "dc_event_destroy": (_I, [_P]),
+    "dc_error_word_read": (_I, [C.POINTER(C.c_int), _I]),
     "dc_version": (C.c_char_p, []),
 }
 
@@ -126,6 +127,22 @@ def lib():
                 fn.argtypes = args
             _lib = l
     return _lib
+
+
+ERROR_WORD_BITS = {1: "gemm_pipe320x16_kernel: LDS counter wait timed out",
+                   2: "flash_attn_d64_pipe_kernel: K/V ring counter wait timed out",
+                   4: "gemm_pp_kernel: LDS counter wait timed out"}
+
+
+def check_error_word(what="", reset=True):
+    """Read (and clear) the library's error word; raise if a kernel reported a timed-out counter wait since the last read -
+    everything computed since then is suspect. Synchronises the device: call at the host's own sync points only."""
+    w = C.c_int(0)
+    check(lib().dc_error_word_read(C.byref(w), 1 if reset else 0), "dc_error_word_read")
+    if w.value:
+        names = [v for k, v in ERROR_WORD_BITS.items() if w.value & k] or [f"unknown bits {w.value:#x}"]
+        raise RuntimeError(f"HIP kernels reported a failed wait ({what or 'error word'} = {w.value:#x}): " + "; ".join(names)
+                           + " - results since the last check are NOT valid")
 
 
 def check(code, what):

@@ -403,7 +403,8 @@ extern "C" int dc_flash_attn_d64(const uint16_t* q, const uint16_t* k, const uin
     hipStream_t stream = (hipStream_t)stream_;
     if (!q || !k || !v || !o) return DC_ERR_ARG;
     if (batch <= 0 || heads <= 0 || Lq <= 0 || Lk <= 0) return DC_ERR_SHAPE;
-    if (ldq % 8 || ldk % 8 || ldv % 8 || ldo % 8 || ((uintptr_t)o & 15)) return DC_ERR_SHAPE;      // 16-byte output stores
+    // 16-byte loads of q / k / v (buffer descriptors in flash_pipe.hip) and 16-byte output stores, also in the accumulate epilogue
+    if (ldq % 8 || ldk % 8 || ldv % 8 || ldo % 8 || (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)o) & 15)) return DC_ERR_SHAPE;
     const float c = scale * 1.4426950408889634f;
     // long self-attention: the one-wave-per-SIMD software-pipelined kernel (flash_pipe.hip); DC_FLASH_PIPE=0 keeps the
     // two-waves-per-SIMD kernel below (same-box A/B)
@@ -435,7 +436,7 @@ extern "C" int dc_cross_attn_dual_d64(const uint16_t* q, const uint16_t* k, cons
     hipStream_t stream = (hipStream_t)stream_;
     if (!q || !k || !v || !k2 || !v2 || !o) return DC_ERR_ARG;
     if (batch <= 0 || heads <= 0 || Lq <= 0 || Lk <= 0 || Lk2 <= 0) return DC_ERR_SHAPE;
-    if (ldq % 8 || ldkv % 8 || ldo % 8 || ((uintptr_t)o & 15)) return DC_ERR_SHAPE;               // 16-byte output stores
+    if (ldq % 8 || ldkv % 8 || ldo % 8 || (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)k2 | (uintptr_t)v2 | (uintptr_t)o) & 15)) return DC_ERR_SHAPE;   // 16-byte loads and stores
     const float c = scale * 1.4426950408889634f;
     const int q_tiles = (Lq + FA_BQ - 1) / FA_BQ;
     const long long nwg = (long long)q_tiles * heads * batch;

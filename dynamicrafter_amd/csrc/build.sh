@@ -9,7 +9,7 @@ FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -I$ROOT/include -I$HERE ${DC_E
 OBJDIR="${DC_OBJDIR:-$HERE}"
 OBJS=()
 pids=()
-SRCS="gemm_conv gemm_conv_glds ff_fused norms attention flash_pipe flash_pipe16 elementwise encoders runtime"
+SRCS="gemm_conv gemm_conv_glds ff_fused norms attention flash_pipe elementwise encoders runtime"
 # objects of kernels that no longer exist must not ride along to the GPU box (or into a link by hand)
 for o in "$OBJDIR"/*.o; do
   [ -e "$o" ] || continue

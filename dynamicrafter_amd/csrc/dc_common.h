@@ -98,11 +98,14 @@ int dc_flash_pipe_launch(const bf16_t* q, const bf16_t* k, const bf16_t* v, bf16
                          int batch, int heads, int Lq, int Lk, int64_t q_bstride, int64_t kv_bstride, float c,
                          hipStream_t stream);
 
-// flash_pipe16.hip: the main pass of the long self-attention on v_mfma_f32_16x16x32_bf16 (Lq % 384 == 0); flags[workgroup] = 1
-// where the shift-0 softmax left its range (dc_flash_pipe_launch then runs the tracking pass for those)
-int dc_flash_x16_launch(const bf16_t* q, const bf16_t* k, const bf16_t* v, bf16_t* o, int ldq, int ldk, int ldv, int ldo,
-                        int batch, int heads, int Lq, int Lk, int64_t q_bstride, int64_t kv_bstride, float c, int* flags,
-                        hipStream_t stream);
+// The library's ERROR WORD (runtime.hip): one int per device. The kernels that synchronise through LDS arrival counters bound
+// every wait (a bookkeeping mistake must not hang the GPU); a wave whose wait ran out ORs its bit into this word before it
+// leaves, so the host can refuse results that were computed past a timed-out wait (dc_error_word_read). Returns the device
+// address for the current device (nullptr on a HIP error); no allocation, no stream operation: safe under stream capture.
+int* dc_error_word_device();
+#define DC_ERRW_GEMM_PIPE 1      // gemm_pipe320x16_kernel: `landed` / `freed` counter wait timed out
+#define DC_ERRW_FLASH_RING 2     // flash_attn_d64_pipe_kernel: K/V ring arrival counter wait timed out
+#define DC_ERRW_GEMM_PP 4        // gemm_pp_kernel (ping-pong GEGLU / plain GEMM): counter wait timed out
 
 // hipFuncAttributeMaxDynamicSharedMemorySize is a PER-DEVICE attribute: kernels with more than 64 KB of dynamic LDS are
 // configured once per device (bit mask; two host threads racing on the first call both set the attribute, which is harmless).

@@ -99,7 +99,7 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1)))
 void flash_attn_d64_pipe_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,
                                 bf16_t* __restrict__ o, int ldq, int ldk, int ldv, int ldo, int heads, int Lq, int Lk,
                                 int64_t q_bstride, int64_t kv_bstride, float c /* scale*log2(e) */, int q_tiles, float thr,
-                                int force_track, const int* __restrict__ only_flagged) {
+                                int force_track, int* __restrict__ err /* the library's error word (runtime.hip) */) {
     static_assert(QB == 2 || QB == 3, "query blocks per wave");
     constexpr int ROWS = 128 * QB;        // query rows per workgroup
     constexpr int NQK = 4 * QB;           // score MFMAs of a step (gaps 0 .. NQK-1)
@@ -112,8 +112,6 @@ void flash_attn_d64_pipe_kernel(const bf16_t* __restrict__ q, const bf16_t* __re
 
     const int nwg = gridDim.x;
     const int id = xcd_remap(blockIdx.x, nwg);
-    // second launch behind flash_attn_d64_x16_kernel (flash_pipe16.hip): only the workgroups whose flag it raised redo their rows
-    if (only_flagged && only_flagged[id] == 0) return;
     const int qt = id % q_tiles;
     const int bh = id / q_tiles;
     const int head = bh % heads;
@@ -261,7 +259,7 @@ void flash_attn_d64_pipe_kernel(const bf16_t* __restrict__ q, const bf16_t* __re
     // In-gap order: the MFMA, this gap's two v_exp_f32, then the pack of the PREVIOUS gap's exponentials, v_max3 in between -
     // no statement directly follows one that produced an operand of it (hipcc pads such pairs of asm statements).
     __attribute__((address_space(3))) int* const ring_cnt = (__attribute__((address_space(3))) int*)(smem + FP_RING);
-    int seen = 0;
+    int seen = 0, gave_up = 0;
     auto step = [&](auto PAR_, auto TR_, auto DEC_, auto QK_, auto MX_, auto EX_, auto PV_, auto NK_, auto NV_, auto RING_,
                     const unsigned (&kn)[4], int knpar, unsigned vn, int vnpar, int tile, int stage) __attribute__((always_inline)) {
         constexpr int PAR = decltype(PAR_)::value, RING = decltype(RING_)::value;
@@ -294,11 +292,17 @@ void flash_attn_d64_pipe_kernel(const bf16_t* __restrict__ q, const bf16_t* __re
             // every tile): a wave ARRIVES by adding 1 to an LDS counter behind its stores of tile T+2 (one wave's LDS operations
             // execute in order: whoever sees the add sees the stores, and the wave's own requests of older tiles have returned),
             // and a step later, before it requests tile T+2, checks that all four have arrived at this iteration - normally
-            // long true; the value is requested four gaps ahead of the check
+            // long true; the value is requested four gaps ahead of the check. Every wave arrives once per step, so the wait always
+            // ends; the bound (about 10 ms, once per wave) keeps a future bookkeeping mistake from hanging the GPU: the wave then
+            // carries on with whatever the ring holds and the kernel reports DC_ERRW_FLASH_RING in the error word
             if constexpr (RING == 2) {
                 if (g == NEX - 4) seen = *(volatile __attribute__((address_space(3))) int*)ring_cnt;
                 if (j == 0) {
-                    while (__builtin_amdgcn_readfirstlane(seen) < tile) seen = *(volatile __attribute__((address_space(3))) int*)ring_cnt;
+                    int spins = 0;
+                    while (!gave_up && __builtin_amdgcn_readfirstlane(seen) < tile) {
+                        seen = *(volatile __attribute__((address_space(3))) int*)ring_cnt;
+                        if (++spins > 200000) gave_up = 1;
+                    }
                     asm volatile("" ::: "memory");
                 }
             }
@@ -504,6 +508,8 @@ void flash_attn_d64_pipe_kernel(const bf16_t* __restrict__ q, const bf16_t* __re
         row_sums();
     }
 
+    if (gave_up && lane == 0) atomicOr(err, DC_ERRW_FLASH_RING);
+
     // ---- epilogue: normalise, bf16, store
 #pragma unroll
     for (int x = 0; x < QB; ++x) {
@@ -545,34 +551,15 @@ extern "C" int dc_fp_debug_stamps(unsigned long long* out, int reset) {
 // pass directly instead of as the fallback; bit 1 = two query blocks per wave (256 rows per workgroup) for every shape (default:
 // three when Lq is a multiple of 384); thr = threshold of the tracking pass, in exp2 units, by which a score must exceed the
 // running max before the state is rescaled (P <= 2^thr otherwise). Initial values from DC_FLASH_TRACK / DC_FLASH_QB2 /
-// DC_FLASH_THR.
-static int g_fp_mode = [] {
-    const char* t = getenv("DC_FLASH_TRACK"); const char* b = getenv("DC_FLASH_QB2"); const char* x = getenv("DC_FLASH_X16");
-    return ((t && t[0] == '1') ? 1 : 0) | ((b && b[0] == '1') ? 2 : 0) | ((x && x[0] == '1') ? 4 : 0);
-}();
-static float g_fp_thr = [] { const char* e = getenv("DC_FLASH_THR"); return e ? (float)atof(e) : 8.0f; }();
+// DC_FLASH_THR. (The 16x16x32 main pass that bit 2 once selected lives in tools/experimental/flash_pipe16.hip.)
+static std::atomic<int> g_fp_mode{[] {
+    const char* t = getenv("DC_FLASH_TRACK"); const char* b = getenv("DC_FLASH_QB2");
+    return ((t && t[0] == '1') ? 1 : 0) | ((b && b[0] == '1') ? 2 : 0);
+}()};
+static std::atomic<float> g_fp_thr{[] { const char* e = getenv("DC_FLASH_THR"); const float v = e ? (float)atof(e) : 8.0f; return (v >= 0.f && v <= 64.f) ? v : 8.0f; }()};
 extern "C" int dc_flash_attn_set_mode(int mode, float thr) {
-    if (mode < 0 || mode > 7 || !(thr >= 0.f) || thr > 64.f) return DC_ERR_ARG;
-    g_fp_mode = mode; g_fp_thr = thr;
-    return 0;
-}
-
-// One flag per workgroup of the 16x16x32 main pass, per device, allocated at the first use (outside any stream capture: the
-// first launch of a process is an eager one) and never freed
-constexpr long long FP_MAX_FLAGS = 1 << 20;
-static int fp_flag_buffer(int** out) {
-    static int* buf[64] = {};
-    int dev = 0;
-    hipError_t e = hipGetDevice(&dev);
-    if (e != hipSuccess) return (int)e;
-    if (dev < 0 || dev >= 64) return DC_ERR_ARG;
-    if (!buf[dev]) {
-        int* p = nullptr;
-        e = hipMalloc(&p, FP_MAX_FLAGS * sizeof(int));
-        if (e != hipSuccess) return (int)e;
-        buf[dev] = p;
-    }
-    *out = buf[dev];
+    if (mode < 0 || mode > 3 || !(thr >= 0.f) || thr > 64.f) return DC_ERR_ARG;
+    g_fp_mode.store(mode, std::memory_order_relaxed); g_fp_thr.store(thr, std::memory_order_relaxed);
     return 0;
 }
 
@@ -581,35 +568,27 @@ static int fp_flag_buffer(int** out) {
 int dc_flash_pipe_launch(const bf16_t* q, const bf16_t* k, const bf16_t* v, bf16_t* o, int ldq, int ldk, int ldv, int ldo,
                          int batch, int heads, int Lq, int Lk, int64_t q_bstride, int64_t kv_bstride, float c,
                          hipStream_t stream) {
-    const float thr = g_fp_thr;
-    const int force_track = g_fp_mode & 1;
+    const float thr = g_fp_thr.load(std::memory_order_relaxed);
+    const int mode = g_fp_mode.load(std::memory_order_relaxed);
+    const int force_track = mode & 1;
+    int* const err = dc_error_word_device();
+    if (!err) return DC_ERR_ARG;
     static DcLdsOnce once2, once3;
     if (const int e = once2.ensure((const void*)flash_attn_d64_pipe_kernel<2>, FP_LDS)) return e;
     if (const int e = once3.ensure((const void*)flash_attn_d64_pipe_kernel<3>, FP_LDS)) return e;
-    const bool qb3 = !(g_fp_mode & 2) && Lq % 384 == 0;
+    const bool qb3 = !(mode & 2) && Lq % 384 == 0;
     const int rows = qb3 ? 384 : 256;
     const int q_tiles = (Lq + rows - 1) / rows;
     const long long nwg = (long long)q_tiles * heads * batch;
     if (nwg > 0x7fffffffLL) return DC_ERR_SHAPE;
     // the byte offsets of the K / V buffer loads are 32-bit
     if ((long long)Lk * ldk * 2 >= 0x7fffffffLL || (long long)Lk * ldv * 2 >= 0x7fffffffLL) return DC_ERR_SHAPE;
-    // mode bit 2: the main pass on v_mfma_f32_16x16x32_bf16 (flash_pipe16.hip: no tracking pass of its own - it flags the
-    // workgroups whose row sums left the shift-0 range, and this kernel's tracking pass redoes exactly those); same 384-row tiling
-    if ((g_fp_mode & 4) && qb3 && !force_track && nwg <= FP_MAX_FLAGS) {
-        int* flags = nullptr;
-        if (const int e = fp_flag_buffer(&flags)) return e;
-        if (const int e = dc_flash_x16_launch(q, k, v, o, ldq, ldk, ldv, ldo, batch, heads, Lq, Lk, q_bstride, kv_bstride, c, flags, stream)) return e;
-        hipLaunchKernelGGL(flash_attn_d64_pipe_kernel<3>, dim3((unsigned)nwg), dim3(256), FP_LDS, stream, q, k, v, o, ldq, ldk, ldv,
-                           ldo, heads, Lq, Lk, q_bstride, kv_bstride, c, q_tiles, thr, 1, (const int*)flags);
-        DC_CHECK_LAUNCH();
-        return 0;
-    }
     if (qb3)
         hipLaunchKernelGGL(flash_attn_d64_pipe_kernel<3>, dim3((unsigned)nwg), dim3(256), FP_LDS, stream, q, k, v, o, ldq, ldk, ldv,
-                           ldo, heads, Lq, Lk, q_bstride, kv_bstride, c, q_tiles, thr, force_track, (const int*)nullptr);
+                           ldo, heads, Lq, Lk, q_bstride, kv_bstride, c, q_tiles, thr, force_track, err);
     else
         hipLaunchKernelGGL(flash_attn_d64_pipe_kernel<2>, dim3((unsigned)nwg), dim3(256), FP_LDS, stream, q, k, v, o, ldq, ldk, ldv,
-                           ldo, heads, Lq, Lk, q_bstride, kv_bstride, c, q_tiles, thr, force_track, (const int*)nullptr);
+                           ldo, heads, Lq, Lk, q_bstride, kv_bstride, c, q_tiles, thr, force_track, err);
     DC_CHECK_LAUNCH();
     return 0;
 }

@@ -65,6 +65,7 @@ struct GemmSplit {
     int splits;
     int tile_begin;
     int tile_count;
+    int* err;          // the library's error word (dc_common.h); set by the launchers of kernels with bounded counter waits
 };
 
 template <int BN, bool GEGLU, int MODE, int GSTAGES>
@@ -593,7 +594,6 @@ __device__ __forceinline__ void persist_tile(int logical, int tiles_m, int tiles
 
 #include "gemm_pipe.h"
 #include "gemm_pipe16.h"
-#include "conv_pipe.h"
 
 template <int BN, bool GEGLU, int GSTAGES, int EPI, int MODE>
 __global__ __launch_bounds__(GNT) void gemm_persist_kernel(const DcGemmParams p, const int tile_group) {
@@ -935,7 +935,7 @@ int launch_glds(const DcGemmParams& p, hipStream_t stream) {
     static DcLdsOnce lds_once;
     if (const int e = lds_once.ensure(reinterpret_cast<const void*>(&gemm_conv_glds_kernel<BN, GEGLU, MODE, GSTAGES>), (int)lds)) return e;
     GemmSplit sp;
-    sp.partial = nullptr; sp.splits = 1; sp.tile_begin = 0; sp.tile_count = tiles_m * tiles_n;
+    sp.partial = nullptr; sp.splits = 1; sp.tile_begin = 0; sp.tile_count = tiles_m * tiles_n; sp.err = nullptr;
     dc_note_variant(GEGLU ? "gemm_conv_glds_kernel<geglu>"
                     : BN == 320 ? (MODE == 0 ? "gemm_conv_glds_kernel<320>" : MODE == 2 ? "gemm_conv_glds_kernel<320,tconv>" : "gemm_conv_glds_kernel<320,conv>")
                     : BN == 256 ? (MODE == 0 ? "gemm_conv_glds_kernel<256>" : MODE == 2 ? "gemm_conv_glds_kernel<256,tconv>" : "gemm_conv_glds_kernel<256,conv>")
@@ -945,31 +945,31 @@ int launch_glds(const DcGemmParams& p, hipStream_t stream) {
     return 0;
 }
 
-// The one-wave-per-SIMD 256 x 320 kernel (gemm_pipe.h) takes a launch when dc_gemm_set_plan selects it and its addressing
+// The one-wave-per-SIMD 256 x 320 kernel (gemm_pipe16.h) takes a launch when dc_gemm_set_plan selects it and its addressing
 // applies: bf16 output through the row-major epilogue, whole 64-channel slices, activation offsets below 2^31.
-// default 11: the one-wave-per-SIMD kernel on v_mfma_f32_16x16x32_bf16 for every 3x3 conv and for the long-K (>= 1920) plain
-// and temporal launches: 10-18 % faster than the 8-wave kernel there (tools/pipe_ab.sh: the chip holds a higher clock on that
-// MFMA shape); short-K launches stay on the persistent kernels
-std::atomic<int> g_gemm_plan{[] { const char* e = getenv("DC_GEMM_PLAN"); return e ? atoi(e) : 11; }()};
+// default 3 (bit 0: every 3x3 conv, bit 1: also the long-K (>= 1920) plain and temporal launches): 10-18 % faster than the
+// 8-wave kernel there (the chip holds a higher clock on v_mfma_f32_16x16x32_bf16); short-K launches stay on the
+// persistent kernels. Bit 3 of older plan values (9 / 11) is accepted and dropped.
+inline bool plan_valid(int plan) { return plan >= 0 && plan <= 15 && !(plan & 4); }
+std::atomic<int> g_gemm_plan{[] {
+    const char* e = getenv("DC_GEMM_PLAN");
+    const int v = e ? atoi(e) : 3;
+    return plan_valid(v) ? (v & 3) : 3;
+}()};
 constexpr int PIPE_MIN_K = 1920;
 
-// plan bit 3: the one-wave-per-SIMD kernel on v_mfma_f32_16x16x32_bf16 (gemm_pipe16.h) instead of 32x32x16
 template <int MODE, int EPI>
-int launch_pipe_shape(const DcGemmParams& p, hipStream_t stream, const GemmSplit& sp, int gx, int gy) {
-    if constexpr (MODE == 3) {
-        return launch_pipe320x16<3, EPI>(p, stream, sp, gx, gy);           // (pipe_ok admits upsampling convs under plan bit 3 only)
-    } else {
-        if (g_gemm_plan.load(std::memory_order_relaxed) & 8) return launch_pipe320x16<MODE, EPI>(p, stream, sp, gx, gy);
-        return launch_pipe320<MODE, EPI>(p, stream, sp, gx, gy);
-    }
+int launch_pipe_shape(const DcGemmParams& p, hipStream_t stream, GemmSplit sp, int gx, int gy) {
+    sp.err = dc_error_word_device();
+    if (!sp.err) return DC_ERR_ARG;
+    return launch_pipe320x16<MODE, EPI>(p, stream, sp, gx, gy);
 }
 
-inline bool pipe_ok(const DcGemmParams& p) {
-    const int plan = g_gemm_plan.load(std::memory_order_relaxed);
+inline bool pipe_ok(const DcGemmParams& p, int plan) {
     if (!(plan & 3) || (!(plan & 2) && p.mode != 1)) return false;
     if (p.mode != 1 && p.K < PIPE_MIN_K) return false;
     if (p.flags & (DC_GEMM_GEGLU | DC_GEMM_OUT_F32)) return false;
-    if (p.ups && !((plan & 8) && p.mode == 1 && p.ups == 1 && p.stride == 1 && p.pad == 1 && p.OH == 2 * p.IH && p.OW == 2 * p.IW)) return false;
+    if (p.ups && !(p.mode == 1 && p.ups == 1 && p.stride == 1 && p.pad == 1 && p.OH == 2 * p.IH && p.OW == 2 * p.IW)) return false;
     if (p.N % 320 != 0 || p.n_pad < p.N || p.K % 64 != 0 || p.lda % 8 != 0 || ((uintptr_t)p.A % 16) != 0) return false;
     if (p.ldc % 8 != 0 || ((uintptr_t)p.C % 16) != 0 || (long long)p.M * p.ldc >= (1ll << 31)) return false;
     if (p.residual && (p.ldr % 8 != 0 || ((uintptr_t)p.residual % 16) != 0 || (long long)p.M * p.ldr >= (1ll << 31))) return false;
@@ -982,35 +982,12 @@ inline bool pipe_ok(const DcGemmParams& p) {
     return true;
 }
 
-// conv_pipe.h: stride-1 3x3 convs with the activation window in LDS (plan bit 2)
-inline bool conv_pipe_ok(const DcGemmParams& p) {
-    if (!(g_gemm_plan.load(std::memory_order_relaxed) & 4) || p.mode != 1 || p.ups || p.stride != 1 || p.pad != 1 || p.OH != p.IH || p.OW != p.IW || p.IW > 135) return false;
-    if (p.flags & (DC_GEMM_GEGLU | DC_GEMM_OUT_F32)) return false;
-    if (p.Cin % 64 != 0 || p.K != 9 * p.Cin || p.N % 320 != 0 || p.n_pad < p.N || p.lda % 8 != 0 || ((uintptr_t)p.A % 16) != 0) return false;
-    if (p.ldc % 8 != 0 || ((uintptr_t)p.C % 16) != 0 || (long long)p.M * p.ldc >= (1ll << 31)) return false;
-    if (p.residual && (p.ldr % 8 != 0 || ((uintptr_t)p.residual % 16) != 0 || (long long)p.M * p.ldr >= (1ll << 31))) return false;
-    if ((long long)p.M * p.lda * 2 >= (1ll << 32) || 320ll * p.K * 2 >= (1ll << 32)) return false;
-    return true;
-}
-
-int launch_conv_pipe_whole(const DcGemmParams& p, hipStream_t stream) {
-    const int ntiles = ((p.M + GBM - 1) / GBM) * (p.N / 320);
-    GemmSplit sp;
-    sp.partial = nullptr; sp.splits = 1; sp.tile_begin = 0; sp.tile_count = ntiles;
-    dc_note_variant("conv3_pipe320_kernel");
-    return p.residual ? launch_conv_pipe<1>(p, stream, sp, ntiles, 1) : launch_conv_pipe<0>(p, stream, sp, ntiles, 1);
-}
-
 int launch_pipe_whole(const DcGemmParams& p, hipStream_t stream) {
-    if (conv_pipe_ok(p)) return launch_conv_pipe_whole(p, stream);
     const int ntiles = ((p.M + GBM - 1) / GBM) * (p.N / 320);
     GemmSplit sp;
-    sp.partial = nullptr; sp.splits = 1; sp.tile_begin = 0; sp.tile_count = ntiles;
-    if (g_gemm_plan.load(std::memory_order_relaxed) & 8)
-        dc_note_variant(p.mode == 0 ? "gemm_pipe320x16_kernel" : p.mode == 2 ? "gemm_pipe320x16_kernel<tconv>"
-                        : p.ups ? "gemm_pipe320x16_kernel<conv,ups>" : "gemm_pipe320x16_kernel<conv>");
-    else
-        dc_note_variant(p.mode == 0 ? "gemm_pipe320_kernel" : p.mode == 2 ? "gemm_pipe320_kernel<tconv>" : "gemm_pipe320_kernel<conv>");
+    sp.partial = nullptr; sp.splits = 1; sp.tile_begin = 0; sp.tile_count = ntiles; sp.err = nullptr;
+    dc_note_variant(p.mode == 0 ? "gemm_pipe320x16_kernel" : p.mode == 2 ? "gemm_pipe320x16_kernel<tconv>"
+                    : p.ups ? "gemm_pipe320x16_kernel<conv,ups>" : "gemm_pipe320x16_kernel<conv>");
     if (p.mode == 0) return p.residual ? launch_pipe_shape<0, 1>(p, stream, sp, ntiles, 1) : launch_pipe_shape<0, 0>(p, stream, sp, ntiles, 1);
     if (p.mode == 1 && p.ups) return p.residual ? launch_pipe_shape<3, 1>(p, stream, sp, ntiles, 1) : launch_pipe_shape<3, 0>(p, stream, sp, ntiles, 1);
     if (p.mode == 1) return p.residual ? launch_pipe_shape<1, 1>(p, stream, sp, ntiles, 1) : launch_pipe_shape<1, 0>(p, stream, sp, ntiles, 1);
@@ -1020,34 +997,17 @@ int launch_pipe_whole(const DcGemmParams& p, hipStream_t stream) {
 // 320-wide tiles with split-K: `full` leading tiles as whole tiles (0 = none), the remaining tiles cut into `splits`
 // K ranges + reduce. Partials: splits * (ntiles - full) * 256 * 320 floats of workspace.
 template <int MODE>
-int launch_glds320_split(const DcGemmParams& p, hipStream_t stream, int ntiles, int full, int splits) {
+int launch_glds320_split(const DcGemmParams& p, hipStream_t stream, int ntiles, int full, int splits, bool use_pipe) {
     constexpr int BN = 320, GSTAGES = 2;
     constexpr size_t lds = (size_t)GSTAGES * (GBM * GBK * 2 + BN * GBK * 2);
     static DcLdsOnce lds_once;
     if (const int e = lds_once.ensure(reinterpret_cast<const void*>(&gemm_conv_glds_kernel<BN, false, MODE, GSTAGES>), (int)lds)) return e;
-    if constexpr (MODE == 1) {
-        if (conv_pipe_ok(p) && p.Cin / 32 >= splits) {
-            dc_note_variant("conv3_pipe320_kernel+splitk");
-            GemmSplit sp;
-            if (full > 0) {
-                sp.partial = nullptr; sp.splits = 1; sp.tile_begin = 0; sp.tile_count = full;
-                if (const int e = p.residual ? launch_conv_pipe<1>(p, stream, sp, full, 1) : launch_conv_pipe<0>(p, stream, sp, full, 1)) return e;
-            }
-            sp.partial = reinterpret_cast<float*>(p.workspace); sp.splits = splits; sp.tile_begin = full; sp.tile_count = ntiles - full;
-            if (const int e = launch_conv_pipe<0>(p, stream, sp, sp.tile_count, splits)) return e;
-            hipLaunchKernelGGL((splitk_reduce_kernel<BN>), dim3((GBM * (BN / 4) + 255) / 256, sp.tile_count), dim3(256), 0, stream, p, sp);
-            DC_CHECK_LAUNCH();
-            return 0;
-        }
-    }
     {
-        if (pipe_ok(p)) {
-            if (g_gemm_plan.load(std::memory_order_relaxed) & 8)
-                dc_note_variant(MODE == 0 ? "gemm_pipe320x16_kernel+splitk" : MODE == 2 ? "gemm_pipe320x16_kernel<tconv>+splitk"
-                                : MODE == 3 ? "gemm_pipe320x16_kernel<conv,ups>+splitk" : "gemm_pipe320x16_kernel<conv>+splitk");
-            else
-                dc_note_variant(MODE == 0 ? "gemm_pipe320_kernel+splitk" : MODE == 2 ? "gemm_pipe320_kernel<tconv>+splitk" : "gemm_pipe320_kernel<conv>+splitk");
+        if (use_pipe) {
+            dc_note_variant(MODE == 0 ? "gemm_pipe320x16_kernel+splitk" : MODE == 2 ? "gemm_pipe320x16_kernel<tconv>+splitk"
+                            : MODE == 3 ? "gemm_pipe320x16_kernel<conv,ups>+splitk" : "gemm_pipe320x16_kernel<conv>+splitk");
             GemmSplit sp;
+            sp.err = nullptr;
             if (full > 0) {
                 sp.partial = nullptr; sp.splits = 1; sp.tile_begin = 0; sp.tile_count = full;
                 if (const int e = p.residual ? launch_pipe_shape<MODE, 1>(p, stream, sp, full, 1) : launch_pipe_shape<MODE, 0>(p, stream, sp, full, 1)) return e;
@@ -1061,6 +1021,7 @@ int launch_glds320_split(const DcGemmParams& p, hipStream_t stream, int ntiles, 
     }
     dc_note_variant(MODE == 0 ? "gemm_conv_glds_kernel<320>+splitk" : MODE == 2 ? "gemm_conv_glds_kernel<320,tconv>+splitk" : "gemm_conv_glds_kernel<320,conv>+splitk");
     GemmSplit sp;
+    sp.err = nullptr;
     if (full > 0) {
         sp.partial = nullptr; sp.splits = 1; sp.tile_begin = 0; sp.tile_count = full;
         hipLaunchKernelGGL((gemm_conv_glds_kernel<BN, false, MODE, GSTAGES>), dim3(full), dim3(GNT), lds, stream, p, sp);
@@ -1104,7 +1065,10 @@ int dc_gemm_conv_glds_try(const DcGemmParams& p, hipStream_t stream) {
     const bool epi16 = out_f32 || ((n_out % 8 == 0) && (p.ldc % 8 == 0) && ((long long)p.M * p.ldc < (1ll << 31)) &&
                                    ((long long)p.M * p.ldr < (1ll << 31)) && ((uintptr_t)p.C % 16 == 0) &&
                                    (!p.residual || ((p.ldr % 8 == 0) && ((uintptr_t)p.residual % 16 == 0))));
-    const bool prefer_pipe = (force == 0) && (pipe_ok(p) || conv_pipe_ok(p));
+    // the plan is read ONCE per dispatch: the label (dc_note_variant) and the kernel always agree, whatever a concurrent
+    // dc_gemm_set_plan does
+    const bool use_pipe = pipe_ok(p, g_gemm_plan.load(std::memory_order_relaxed));
+    const bool prefer_pipe = (force == 0) && use_pipe;
     if (persist && force == 0 && p.mode == 0 && epi16 && p.K <= persist_max_k() && !prefer_pipe) {
         // one workgroup per CU; needs at least 2 output tiles per workgroup to have anything to overlap
         static const int wide = [] { const char* e = getenv("DC_GEMM_PERSIST_WIDE"); return e ? atoi(e) : 1; }();
@@ -1169,24 +1133,24 @@ int dc_gemm_conv_glds_try(const DcGemmParams& p, hipStream_t stream) {
         }
         const size_t need = (size_t)splits * (size_t)(w320 - full) * GBM * 320 * sizeof(float);
         if (splits >= 2 && nk / splits >= (full ? 8 : 12) && need <= (size_t)p.workspace_bytes) {
-            if (p.mode == 0) return launch_glds320_split<0>(p, stream, w320, full, splits);
-            if (p.mode == 1) return p.ups ? launch_glds320_split<3>(p, stream, w320, full, splits)
-                                          : launch_glds320_split<1>(p, stream, w320, full, splits);
-            return launch_glds320_split<2>(p, stream, w320, full, splits);
+            if (p.mode == 0) return launch_glds320_split<0>(p, stream, w320, full, splits, use_pipe);
+            if (p.mode == 1) return p.ups ? launch_glds320_split<3>(p, stream, w320, full, splits, use_pipe)
+                                          : launch_glds320_split<1>(p, stream, w320, full, splits, use_pipe);
+            return launch_glds320_split<2>(p, stream, w320, full, splits, use_pipe);
         }
     }
-    if (force == 320 && n320) return (pipe_ok(p) || conv_pipe_ok(p)) ? launch_pipe_whole(p, stream) : launch_glds_mode<320, 2>(p, stream);
+    if (force == 320 && n320) return use_pipe ? launch_pipe_whole(p, stream) : launch_glds_mode<320, 2>(p, stream);
     if (force == 128 && w128 > 0 && waste128 <= 1.15f) return launch_glds_mode<128, 3>(p, stream);
     if (force == 1) return -100;
     // 256-wide plain tile for the AutoencoderKL widths (N = 256 / 512: not multiples of 320)
     const int w256 = (!n320 && p.N % 256 == 0 && p.n_pad >= p.N) ? tiles_m * (p.N / 256) : 0;
     if ((force == 256 || force == 0) && w256 >= 200 && 1.2f * wave_eff(w256) >= s128) return launch_glds_mode<256, 2>(p, stream);
-    if (s320 > 0.f && s320 >= s128) return (pipe_ok(p) || conv_pipe_ok(p)) ? launch_pipe_whole(p, stream) : launch_glds_mode<320, 2>(p, stream);
+    if (s320 > 0.f && s320 >= s128) return use_pipe ? launch_pipe_whole(p, stream) : launch_glds_mode<320, 2>(p, stream);
     if (s128 > 0.f && waste128 <= 1.15f) return launch_glds_mode<128, 3>(p, stream);
     return -100;
 }
 
 extern "C" int dc_gemm_set_plan(int plan) {
-    if (plan < 0 || plan > 15) return DC_ERR_ARG;
-    return g_gemm_plan.exchange(plan, std::memory_order_relaxed);
+    if (!plan_valid(plan)) return DC_ERR_ARG;
+    return g_gemm_plan.exchange(plan & 3, std::memory_order_relaxed);
 }

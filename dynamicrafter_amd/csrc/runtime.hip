@@ -48,4 +48,33 @@ extern "C" int dc_event_elapsed_ms(void* a, void* b, float* ms) {
 }
 extern "C" int dc_event_destroy(void* ev) { return (int)hipEventDestroy((hipEvent_t)ev); }
 
+// ---- error word (dc_common.h): a __device__ int of this code object; its address per device is looked up once
+__device__ int g_dc_error_word = 0;
+
+int* dc_error_word_device() {
+    static std::atomic<int*> addr[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    int* p = addr[dev].load(std::memory_order_acquire);
+    if (!p) {
+        void* sym = nullptr;
+        if (hipGetSymbolAddress(&sym, HIP_SYMBOL(g_dc_error_word)) != hipSuccess || !sym) return nullptr;
+        p = static_cast<int*>(sym);
+        addr[dev].store(p, std::memory_order_release);
+    }
+    return p;
+}
+
+extern "C" int dc_error_word_read(int* out, int reset) {
+    if (!out) return DC_ERR_ARG;
+    int* const p = dc_error_word_device();
+    if (!p) return DC_ERR_ARG;
+    hipError_t e = hipDeviceSynchronize();
+    if (e != hipSuccess) return (int)e;
+    e = hipMemcpy(out, p, sizeof(int), hipMemcpyDeviceToHost);
+    if (e != hipSuccess) return (int)e;
+    if (reset && *out) e = hipMemset(p, 0, sizeof(int));
+    return (int)e;
+}
+
 extern "C" const char* dc_version(void) { return "dcrafter_hip 0.1 (gfx950)"; }

@@ -18,7 +18,7 @@ behaves as the reference's, including the 3-branch guidance of ddim_multiplecond
 import numpy as np
 import torch
 
-from .... import ops
+from .... import _hip, ops
 from ..utils_diffusion import make_ddim_sampling_parameters, make_ddim_timesteps
 
 
@@ -101,10 +101,13 @@ class FusedRun:
         torch.cuda.synchronize()
 
     def sync(self):
+        """Wait for the issued steps, then read the library's error word: a kernel whose bounded LDS-counter wait timed out
+        (csrc/gemm_pipe.h) has produced garbage, and that must not leave the sampler silently."""
         if self.graph is not None:
             self.graph.sync()
         else:
             torch.cuda.current_stream().synchronize()
+        _hip.check_error_word("FusedRun.sync")
 
 
 class DDIMSampler(object):
@@ -210,16 +213,20 @@ class DDIMSampler(object):
         eta_on = bool((self._tables["sigma_t"] != 0).any().item())
         q_noises = kwargs.pop("q_noises", None)
         draw_q = mask is not None and not clean_cond and q_noises is None
-        if (noises is None and eta_on) or draw_q:
+        if noises is None or draw_q:
             # drawn up front so a captured graph can index them by the device step counter - in the order of the reference's
             # per-step draws: with a mask, q_sample's randn_like of step i comes before that step's noise_like
-            # (ddim.py:174-180, then p_sample_ddim :270)
+            # (ddim.py:174-180, then p_sample_ddim :270). The reference calls noise_like on EVERY step, also when sigma_t = 0
+            # (eta = 0): the draw is then made and discarded here too, so the generator - and with a mask the q_sample noises
+            # of the later steps - stays in step with the reference for the same seed.
             qs, ns = [], []
             for _ in range(S):
                 if draw_q:
                     qs.append(torch.randn(shape, device=dev))
-                if noises is None and eta_on:
-                    ns.append(torch.randn(shape, device=dev))
+                if noises is None:
+                    n_i = torch.randn(shape, device=dev)
+                    if eta_on:
+                        ns.append(n_i)
             if qs:
                 q_noises = torch.stack(qs)
             if ns:

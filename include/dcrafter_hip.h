@@ -58,13 +58,14 @@ typedef struct DcGemmParams {
  * stateless. */
 const char* dc_gemm_last_variant(void);
 
-/* Which kernels take the launches with 320-wide tiles. bit 0: the one-wave-per-SIMD kernel (gemm_pipe.h: activations straight
- * into registers, no barrier in the K loop) for the 3x3 convs, bit 1: also for plain / temporal launches with K >= 1920, bit 3:
- * that kernel on v_mfma_f32_16x16x32_bf16 instead of 32x32x16 (gemm_pipe16.h), bit 2: stride-1 3x3 convs with the activation
- * window of a tile resident in LDS (conv_pipe.h: the nine taps of a channel slice share one staging). Default 11 (bits 0, 1, 3):
- * the matrix pipe is power-managed on MI355X and holds a higher clock on the 16x16x32 shape. 0 = the 8-wave LDS-DMA
- * kernels everywhere. All plans give the same results to bf16 rounding and each is bit-reproducible. Process-wide (env
- * DC_GEMM_PLAN sets the initial value). Returns the previous plan, or DC_ERR_ARG. */
+/* Which kernels take the launches with 320-wide tiles. bit 0: the one-wave-per-SIMD kernel on v_mfma_f32_16x16x32_bf16
+ * (gemm_pipe16.h: activations straight into registers, no barrier in the K loop) for the 3x3 convs, bit 1: also for plain /
+ * temporal launches with K >= 1920. Default 3: the matrix pipe is power-managed on MI355X and holds a higher clock on the
+ * 16x16x32 shape. 0 = the 8-wave LDS-DMA kernels everywhere. Bit 3 is accepted and ignored (it once chose between
+ * the two MFMA shapes of that kernel: plans 9 / 11 = 1 / 3); bit 2 is rejected (the 32x32x16 form and the LDS-window conv kernel
+ * lost every measured shape and live in tools/experimental). Both plans give the same results to bf16 rounding and each is
+ * bit-reproducible. Process-wide (env DC_GEMM_PLAN sets the initial value, validated the same way). Returns the previous plan,
+ * or DC_ERR_ARG. */
 int dc_gemm_set_plan(int plan);
 
 /* Recommended size of DcGemmParams.workspace (one buffer per stream; contents are scratch, no initialisation). */
@@ -107,10 +108,9 @@ int dc_flash_attn_d64(const uint16_t* q, const uint16_t* k, const uint16_t* v, u
 /* Test / measurement hook for the long self-attention path of dc_flash_attn_d64 (Lq >= 512, Lk >= 256, Lk % 64 == 0, no
  * accumulate: the one-wave-per-SIMD pipelined kernel, which runs softmax without a running maximum and repeats a workgroup's
  * block with a running-max pass when a row sum leaves [2^-100, 2^100)). mode bit 0: run the running-max pass directly; bit 1:
- * two 32-row query blocks per wave for every shape (default: three when Lq % 384 == 0); bit 2: the main pass on
- * v_mfma_f32_16x16x32_bf16 (Lq % 384 == 0; a second launch runs the running-max pass for the workgroups it flags); thr (0..64, exp2 units): how far a
- * score must exceed the running max before that pass rescales its state. Process-wide; default mode 0, thr 8.
- * Returns 0 or DC_ERR_ARG. */
+ * two 32-row query blocks per wave for every shape (default: three when Lq % 384 == 0); thr (0..64, exp2 units): how far a
+ * score must exceed the running max before that pass rescales its state. Process-wide (atomics: a launch reads each once);
+ * default mode 0, thr 8. Returns 0 or DC_ERR_ARG (mode outside 0..3). */
 int dc_flash_attn_set_mode(int mode, float thr);
 
 /* Temporal self-attention over T <= 16 frames, head_dim 64: for every (clip b, position p, head h) the T rows
@@ -328,6 +328,14 @@ int dc_event_create(void** ev_out);
 int dc_event_record(void* ev, void* stream);
 int dc_event_elapsed_ms(void* ev_start, void* ev_stop, float* ms_out); /* synchronises on ev_stop */
 int dc_event_destroy(void* ev);
+
+/* The library's error word. Kernels that synchronise through LDS arrival counters (the one-wave-per-SIMD GEMM / conv kernel,
+ * the ping-pong GEMM, the long self-attention) bound every wait so that a bookkeeping mistake cannot hang the GPU; a wave whose
+ * wait ran out ORs a bit into one device word (1: gemm_pipe320x16, 2: flash attention K/V ring, 4: gemm_pp) and its results
+ * are then NOT valid. This entry synchronises the device, copies the word to *out and, if `reset`, clears it. It is the one
+ * entry that synchronises and is not capturable: call it at the host's own sync points (the sampler does after a run, bench.py
+ * before it prints). Returns 0 or a hipError_t / DC_ERR_ARG. */
+int dc_error_word_read(int* out, int reset);
 
 const char* dc_version(void);
 

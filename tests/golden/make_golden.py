@@ -560,10 +560,56 @@ def gen_harness_interp512():
          kwargs=np.array(yaml.safe_dump(kw)))
 
 
+def gen_trajectory_fullwidth():
+    """BASELINE.json config 1 as SURVEY 8(d) specifies it, run by the REFERENCE: inference_256_v1.0.yaml with the released
+    1.44 B-parameter UNet (recipe weights), latent 16x32x32, 10 DDIM steps, `uniform`, CFG 7.5, injected x_T - once with
+    eta = 0 and once with eta = 1 + injected per-step noises. The whole sampler runs (DDIMSampler.sample ->
+    apply_model('hybrid') -> UNetModel), cond and uncond as two batch-1 forwards per step as the reference issues them.
+    Stored: the inputs, x after steps 1 / 5 / 10 and pred_x0 at the same steps. The context is rounded to fp16 BEFORE the
+    reference sees it (stored as fp16, exact); the eta = 1 noises are seeded torch.randn draws (seeds + a checksum stored)."""
+    import time
+    import lvdm.models.samplers.ddim as ddim_mod
+    Sampler = cpu_sampler_cls(ddim_mod.DDIMSampler)
+    model, p = build_lvd("inference_256_v1.0.yaml", None, TINY_AE)
+    load_recipe_weights(model.model.diffusion_model, seed=12)
+    b, t, h, w = 1, 16, 32, 32
+    S = 10
+    x_T = rnd(b, 4, t, h, w, seed=211)
+    ctx = rnd(b, 77 + 16 * t, 1024, seed=212).half().float()
+    uctx = rnd(b, 77 + 16 * t, 1024, seed=214).half().float()
+    cc = (rnd(b, 4, 1, h, w, seed=213) * 0.18215 * 4).repeat(1, 1, t, 1, 1)
+    cond = {"c_crossattn": [ctx], "c_concat": [cc]}
+    uc = {"c_crossattn": [uctx], "c_concat": [cc]}
+    fs = torch.tensor([p["unet_config"]["params"]["default_fs"]] * b, dtype=torch.long)
+    seeds = [2200 + i for i in range(S)]
+    out = dict(x_T=x_T, ctx=ctx.half(), uc_ctx=uctx.half(), c_concat=cc[:, :, :1], fs=fs.numpy(),
+               noise_seeds=np.array(seeds), keep=np.array([1, 5, 10]),
+               yaml_unet=np.array(yaml.safe_dump(p["unet_config"]["params"])))
+    for tag, eta in (("eta0", 0.0), ("eta1", 1.0)):
+        noises = [rnd(b, 4, t, h, w, seed=sd) for sd in seeds]
+        it = iter(noises)
+        ddim_mod.noise_like = lambda shp, dev, rep=False: next(it)
+        s = Sampler(model)
+        t0 = time.time()
+        with torch.no_grad():
+            samples, inter = s.sample(S=S, batch_size=b, shape=(4, t, h, w), conditioning=cond, verbose=False,
+                                      unconditional_guidance_scale=7.5, unconditional_conditioning=uc, eta=eta,
+                                      x_T=x_T, fs=fs, timestep_spacing="uniform", guidance_rescale=0.0, log_every_t=1)
+        print(f"  reference 10-step run {tag}: {time.time() - t0:.1f} s")
+        xi, pi = inter["x_inter"], inter["pred_x0"]          # index 0 = x_T, index k = after step k
+        assert len(xi) == S + 1 and torch.equal(xi[S], samples)
+        for k in (1, 5, 10):
+            out[f"{tag}/x_{k}"] = xi[k]
+            out[f"{tag}/pred_x0_{k}"] = pi[k]
+        out[f"{tag}/noise_checksum"] = np.array([float(n.double().sum()) for n in noises])
+    save("trajectory_fullwidth_256", **out)
+
+
 GENS = dict(resampler=gen_resampler, unet_tiny=gen_unet_tiny, unet_fullwidth=gen_unet_fullwidth, ae=gen_ae, schedules=gen_schedules,
             p_sample=gen_p_sample_known_answers, trajectory=gen_trajectory, first_stage=gen_first_stage,
             harness=gen_harness, unet_fullsize=gen_unet_fullsize, trajectory50=gen_trajectory50,
-            sampler_extras=gen_sampler_extras, harness_interp512=gen_harness_interp512)
+            sampler_extras=gen_sampler_extras, harness_interp512=gen_harness_interp512,
+            trajectory_fullwidth=gen_trajectory_fullwidth)
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()

@@ -1,0 +1,82 @@
+"""A timed-out LDS-counter wait must be LOUD (VERDICT r3 weak 4 / ADVICE r3 medium): the one-wave-per-SIMD GEMM / conv kernel
+and the long self-attention bound every counter wait, and a wave whose wait ran out ORs a bit into the library's error word,
+which the host reads at its sync points (FusedRun.sync, bench.py) and raises on.
+
+The failing case needs a kernel that really loses an arrival: tools/build_variant.sh builds the library with
+-DGP_DBG_SKIP_POST (wave 3 of gemm_pipe320x16_kernel forgets one `landed` post) into tools/_variants/libdc_skip_post.so
+(__graft_entry__.build() does it; built here if absent). The library path is read at import, so the case runs in ONE child
+process, once - the kernel must return (no hang), the word must be set, the host must raise, and a second read must be clean."""
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+VARIANT = os.path.join(ROOT, "tools", "_variants", "libdc_skip_post.so")
+
+CHILD = r"""
+import sys, torch
+sys.path.insert(0, %(root)r)
+from dynamicrafter_amd import _hip, ops
+DEV = "cuda:0"
+n, C, Co, H, W = 64, 128, 320, 32, 32                     # 256 row tiles x 1, K = 18 tiles of 64: whole tiles on gemm_pipe320x16
+g = torch.Generator(device=DEV).manual_seed(1)
+x = torch.randn(n * H * W, C, device=DEV, generator=g).to(torch.bfloat16)
+w = torch.randn(Co, C, 3, 3, device=DEV, generator=g) * (9 * C) ** -0.5
+pw = ops.PackedWeight.conv3x3(w.cpu(), torch.zeros(Co), DEV)
+out = torch.empty(n * H * W, Co, dtype=torch.bfloat16, device=DEV)
+_hip.check_error_word("before")                           # clean at start
+ops.gemm(x, pw, out, conv=dict(IH=H, IW=W, OH=H, OW=W, stride=1, pad=1, ups=0))
+assert "gemm_pipe320x16" in _hip.lib().dc_gemm_last_variant().decode()
+torch.cuda.synchronize()                                   # the kernel RETURNED: the bounded waits ended
+try:
+    _hip.check_error_word("after the conv")
+except RuntimeError as e:
+    assert "gemm_pipe320x16_kernel" in str(e) and "NOT valid" in str(e), str(e)
+    print("RAISED", flush=True)
+else:
+    print("SILENT", flush=True)
+_hip.check_error_word("second read")                       # the read cleared the word
+print("CLEARED", flush=True)
+"""
+
+
+def _run_child(lib):
+    env = dict(os.environ)
+    if lib:
+        env["DC_HIP_LIB"] = lib
+    else:
+        env.pop("DC_HIP_LIB", None)
+    for k in ("DC_GEMM_PLAN", "DC_GEMM_TILE", "DC_GEMM_SPLITK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, "-c", CHILD % dict(root=ROOT)], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    return r.stdout
+
+
+def test_lost_counter_post_is_reported():
+    if not os.path.exists(VARIANT):
+        subprocess.run(["bash", os.path.join(ROOT, "tools", "build_variant.sh"), "skip_post", "-DGP_DBG_SKIP_POST", "gemm_conv_glds"],
+                       check=True, timeout=900)
+    out = _run_child(VARIANT)
+    assert "RAISED" in out and "CLEARED" in out, out
+
+
+def test_product_library_leaves_the_word_clean():
+    out = _run_child(None)
+    assert "SILENT" in out and "CLEARED" in out, out
+
+
+def test_fused_run_sync_reads_the_word(monkeypatch):
+    """FusedRun.sync() is the sampler's sync point: it must go through _hip.check_error_word."""
+    from dynamicrafter_amd import _hip
+    from dynamicrafter_amd.lvdm.models.samplers.ddim import FusedRun
+    seen = []
+    monkeypatch.setattr(_hip, "check_error_word", lambda what="", reset=True: seen.append(what))
+    run = FusedRun.__new__(FusedRun)
+    run.graph = None
+    run.sync()
+    assert seen == ["FusedRun.sync"]

@@ -487,6 +487,24 @@ def test_sampler_mask_default_noise_draw_order_and_graph_bookkeeping():
     assert torch.equal(a, b)
     with pytest.raises(ValueError):                           # a noise buffer shorter than S steps is refused up front
         DDIMSampler(model).sample(noises=torch.stack(ns[:3]), q_noises=torch.stack(qs), **kw)
+    # eta = 0 with a mask: the reference still calls noise_like every step (ddim.py:270; sigma_t = 0 discards the value), so
+    # q_sample's draws stay interleaved with one discarded draw per step - same seed, same q noises as the hand-drawn order
+    kw0 = dict(kw, eta=0.0)
+    torch.manual_seed(777)
+    a0, _ = DDIMSampler(model).sample(**kw0)
+    torch.manual_seed(777)
+    qs0 = []
+    for _ in range(S):
+        qs0.append(torch.randn(x_T.shape, device=DEV)); torch.randn(x_T.shape, device=DEV)
+    b0, _ = DDIMSampler(model).sample(q_noises=torch.stack(qs0), **kw0)
+    assert torch.equal(a0, b0)
+    torch.manual_seed(777)                                    # without a mask the generator advances by S draws as well
+    DDIMSampler(model).sample(**dict(kw0, mask=None, x0=None))
+    after = torch.randn(4, device=DEV)
+    torch.manual_seed(777)
+    for _ in range(S):
+        torch.randn(x_T.shape, device=DEV)
+    assert torch.equal(after, torch.randn(4, device=DEV))
     # bookkeeping under the captured graph == eager
     rec = {}
     for use_graph in (False, True):

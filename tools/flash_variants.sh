@@ -10,7 +10,7 @@ FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -I$ROOT/include -I$CS"
 build() {  # name, extra flags
   /opt/rocm/bin/hipcc $FLAGS $2 -c "$CS/flash_pipe.hip" -o "$OUT/flash_pipe_$1.o"
   OBJS=""
-  for f in gemm_conv gemm_conv_glds ff_fused norms attention flash_pipe16 elementwise encoders runtime; do OBJS="$OBJS $CS/$f.o"; done
+  for f in gemm_conv gemm_conv_glds ff_fused norms attention elementwise encoders runtime; do OBJS="$OBJS $CS/$f.o"; done
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o "$OUT/libdc_$1.so" $OBJS "$OUT/flash_pipe_$1.o"
   rm -f "$OUT/flash_pipe_$1.o"
 }

@@ -10,7 +10,7 @@ FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -I$ROOT/include -I$CS"
 build() {  # name, extra flags
   /opt/rocm/bin/hipcc $FLAGS $2 -c "$CS/gemm_conv_glds.hip" -o "$OUT/gcg_$1.o"
   OBJS=""
-  for f in gemm_conv ff_fused norms attention flash_pipe flash_pipe16 elementwise encoders runtime; do OBJS="$OBJS $CS/$f.o"; done
+  for f in gemm_conv ff_fused norms attention flash_pipe elementwise encoders runtime; do OBJS="$OBJS $CS/$f.o"; done
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o "$OUT/libdc_gp_$1.so" $OBJS "$OUT/gcg_$1.o"
   rm -f "$OUT/gcg_$1.o"
 }
