@@ -142,11 +142,13 @@ def p_sample_ddim(sched: DDIMSchedule, x, index, e_cond, e_uncond=None, e_img=No
 @torch.no_grad()
 def ddim_sample(apply_model, sched: DDIMSchedule, x_T, cond, uncond=None, *, cfg_scale=1.0, guidance_rescale=0.0,
                 noises=None, temperature=1.0, uncond_img=None, cfg_img=None, mask=None, x0=None, clean_cond=False,
-                q_noises=None, t_start=None, **model_kwargs):
+                q_noises=None, t_start=None, trace=None, **model_kwargs):
     """DDIMSampler.ddim_sampling ddim.py:134-203 with injected x_T / per-step noise.
     apply_model(x, t_long[b], cond_dict, **model_kwargs) -> model output.
     mask / x0 (:174-180): before every step the latent is blended with the (re-noised, unless clean_cond) original;
-    q_noises[i] is the q_sample draw of step i. t_start: run only the last t_start DDIM steps (decode, :281-301)."""
+    q_noises[i] is the q_sample draw of step i. t_start: run only the last t_start DDIM steps (decode, :281-301).
+    trace: a list that receives (x after the step, pred_x0) per step - the reference's `intermediates` with log_every_t = 1
+    (:199-201); a callable is called with (i, x, pred_x0) instead."""
     img = x_T
     b = img.shape[0]
     ts = sched.ddim_timesteps if t_start is None else sched.ddim_timesteps[:t_start]
@@ -164,9 +166,13 @@ def ddim_sample(apply_model, sched: DDIMSchedule, x_T, cond, uncond=None, *, cfg
             if uncond_img is not None:                    # 3-branch guidance (ddim_multiplecond.py:230-234)
                 e_i = apply_model(img, tl, uncond_img, **model_kwargs)
         nz = None if noises is None else noises[i]
-        img, _ = p_sample_ddim(sched, img, index, e_c, e_u, e_i, cfg_scale=cfg_scale,
-                               cfg_img=cfg_scale if cfg_img is None else cfg_img, guidance_rescale=guidance_rescale,
-                               noise=nz, temperature=temperature)
+        img, pred_x0 = p_sample_ddim(sched, img, index, e_c, e_u, e_i, cfg_scale=cfg_scale,
+                                     cfg_img=cfg_scale if cfg_img is None else cfg_img, guidance_rescale=guidance_rescale,
+                                     noise=nz, temperature=temperature)
+        if callable(trace):
+            trace(i, img, pred_x0)
+        elif trace is not None:
+            trace.append((img, pred_x0))
     return img
 
 

@@ -361,3 +361,41 @@ def test_clip_oracle_blocks_match_torch_modules():
     # a constant image stays constant through blur + bicubic (both kernels sum to 1)
     c = oclip.preprocess(torch.full((1, 3, 320, 512), 0.25))
     assert maxrel(c, ((torch.full((1, 3, 224, 224), 0.25) + 1) / 2 - mean) / std) < 1e-5
+
+
+def fullwidth_trajectory_inputs(g):
+    """Inputs of tests/golden/trajectory_fullwidth_256.npz as the reference saw them (make_golden.gen_trajectory_fullwidth): the
+    context is stored as fp16 (it was rounded before the reference run), the concat latent is one frame repeated over T, the
+    eta = 1 noises are seeded torch.randn draws whose checksums the fixture carries."""
+    x_T = T(g["x_T"])
+    t = x_T.shape[2]
+    cc = T(g["c_concat"]).repeat(1, 1, t, 1, 1)
+    ctx, uctx = T(g["ctx"]).float(), T(g["uc_ctx"]).float()
+    noises = [torch.randn(*x_T.shape, generator=torch.Generator().manual_seed(int(sd))) for sd in g["noise_seeds"]]
+    chk = np.array([float(n.double().sum()) for n in noises])
+    assert np.allclose(chk, g["eta1/noise_checksum"], rtol=0, atol=1e-9), "torch.randn stream differs from the fixture's"
+    return x_T, cc, ctx, uctx, T(g["fs"]), noises
+
+
+def test_trajectory_fullwidth_first_step_matches_reference():
+    """BASELINE config 1 at FULL width, as the reference ran it (inference_256, 1.44 B parameters, latent 16x32x32, DDIM 10
+    `uniform`, CFG 7.5): the oracle's first step - two full-width forwards + the guided update - against the reference's x_1 and
+    pred_x0_1, eta = 0 and eta = 1 (same forwards, different update). The other nine steps are replayed on the GPU box
+    (tests/test_fullsize_gpu.py: oracle vs fixture AND HIP vs fixture over all ten), where sixteen cores make them affordable."""
+    g = load("trajectory_fullwidth_256")
+    params = yaml.safe_load(str(g["yaml_unet"]))
+    cfg = ounet.UNetCfg.from_params(params)
+    sd = fill_state_dict(ounet.unet_param_shapes(cfg), seed=12)
+    x_T, cc, ctx, uctx, fs, noises = fullwidth_trajectory_inputs(g)
+    ms = _ms_for("256")
+    am = lambda x, t, c, fs=None: ounet.unet_forward(sd, cfg, torch.cat([x, cc], 1), t, c, fs)
+    sc0 = oddim.DDIMSchedule(ms, 10, "uniform", 0.0)
+    step = int(np.flip(sc0.ddim_timesteps)[0])
+    tl = torch.full((1,), step, dtype=torch.long)
+    e_c, e_u = am(x_T, tl, ctx, fs=fs), am(x_T, tl, uctx, fs=fs)
+    for tag, eta in (("eta0", 0.0), ("eta1", 1.0)):
+        sc = oddim.DDIMSchedule(ms, 10, "uniform", eta)
+        x1, p1 = oddim.p_sample_ddim(sc, x_T, 9, e_c, e_u, None, cfg_scale=7.5, cfg_img=7.5, guidance_rescale=0.0,
+                                     noise=noises[0] if eta > 0 else None, temperature=1.0)
+        assert maxrel(x1, g[f"{tag}/x_1"]) < 1e-4, tag
+        assert maxrel(p1, g[f"{tag}/pred_x0_1"]) < 1e-4, tag
