@@ -258,9 +258,9 @@ __global__ __launch_bounds__(NTHREADS) void gemm_conv_kernel(const DcGemmParams 
                     const float4 bg = *reinterpret_cast<const float4*>(p.bias + (p.N >> 1) + n);
                     g.x += bg.x; g.y += bg.y; g.z += bg.z; g.w += bg.w;
                 }
-                v.x *= gelu_erf_f(g.x); v.y *= gelu_erf_f(g.y); v.z *= gelu_erf_f(g.z); v.w *= gelu_erf_f(g.w);
+                v.x *= DC_GELU(g.x); v.y *= DC_GELU(g.y); v.z *= DC_GELU(g.z); v.w *= DC_GELU(g.w);
             }
-            if (p.flags & DC_GEMM_GELU) { v.x = gelu_erf_f(v.x); v.y = gelu_erf_f(v.y); v.z = gelu_erf_f(v.z); v.w = gelu_erf_f(v.w); }
+            if (p.flags & DC_GEMM_GELU) { v.x = DC_GELU(v.x); v.y = DC_GELU(v.y); v.z = DC_GELU(v.z); v.w = DC_GELU(v.w); }
             if (p.rowvec) {
                 const float4 rv = *reinterpret_cast<const float4*>(p.rowvec + (size_t)(m / p.rows_per_vec) * p.rowvec_ld + n);
                 v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;

@@ -357,9 +357,9 @@ __global__ __launch_bounds__(GNT) void gemm_conv_glds_kernel(const DcGemmParams 
                     const float4 bg = *reinterpret_cast<const float4*>(p.bias + (p.N >> 1) + n);
                     g.x += bg.x; g.y += bg.y; g.z += bg.z; g.w += bg.w;
                 }
-                v.x *= gelu_erf_f(g.x); v.y *= gelu_erf_f(g.y); v.z *= gelu_erf_f(g.z); v.w *= gelu_erf_f(g.w);
+                v.x *= DC_GELU(g.x); v.y *= DC_GELU(g.y); v.z *= DC_GELU(g.z); v.w *= DC_GELU(g.w);
             }
-            if (p.flags & DC_GEMM_GELU) { v.x = gelu_erf_f(v.x); v.y = gelu_erf_f(v.y); v.z = gelu_erf_f(v.z); v.w = gelu_erf_f(v.w); }
+            if (p.flags & DC_GEMM_GELU) { v.x = DC_GELU(v.x); v.y = DC_GELU(v.y); v.z = DC_GELU(v.z); v.w = DC_GELU(v.w); }
             if (p.rowvec) {
                 const float4 rv = *reinterpret_cast<const float4*>(p.rowvec + (size_t)(m / p.rows_per_vec) * p.rowvec_ld + n);
                 v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
@@ -408,7 +408,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const DcGemmParams p
         const float4 bv = *reinterpret_cast<const float4*>(p.bias + n);
         v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
     }
-    if (p.flags & DC_GEMM_GELU) { v.x = gelu_erf_f(v.x); v.y = gelu_erf_f(v.y); v.z = gelu_erf_f(v.z); v.w = gelu_erf_f(v.w); }
+    if (p.flags & DC_GEMM_GELU) { v.x = DC_GELU(v.x); v.y = DC_GELU(v.y); v.z = DC_GELU(v.z); v.w = DC_GELU(v.w); }
     if (p.rowvec) {
         const float4 rv = *reinterpret_cast<const float4*>(p.rowvec + (size_t)(m / p.rows_per_vec) * p.rowvec_ld + n);
         v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
@@ -483,9 +483,9 @@ __device__ __forceinline__ void persist_epilogue(f32x16_t (&acc)[2][BN / 64], co
                 const float4 bg = *reinterpret_cast<const float4*>(p.bias + (p.N >> 1) + n);
                 gt.x += bg.x; gt.y += bg.y; gt.z += bg.z; gt.w += bg.w;
             }
-            v.x *= gelu_erf_f(gt.x); v.y *= gelu_erf_f(gt.y); v.z *= gelu_erf_f(gt.z); v.w *= gelu_erf_f(gt.w);
+            v.x *= DC_GELU(gt.x); v.y *= DC_GELU(gt.y); v.z *= DC_GELU(gt.z); v.w *= DC_GELU(gt.w);
         }
-        if (p.flags & DC_GEMM_GELU) { v.x = gelu_erf_f(v.x); v.y = gelu_erf_f(v.y); v.z = gelu_erf_f(v.z); v.w = gelu_erf_f(v.w); }
+        if (p.flags & DC_GEMM_GELU) { v.x = DC_GELU(v.x); v.y = DC_GELU(v.y); v.z = DC_GELU(v.z); v.w = DC_GELU(v.w); }
         if (rv && nok) {
             const float4 r4 = *reinterpret_cast<const float4*>(rv + n);
             v.x += r4.x; v.y += r4.y; v.z += r4.z; v.w += r4.w;
@@ -594,6 +594,7 @@ __device__ __forceinline__ void persist_tile(int logical, int tiles_m, int tiles
 
 #include "gemm_pipe.h"
 #include "gemm_pipe16.h"
+#include "gemm_pp.h"
 
 template <int BN, bool GEGLU, int GSTAGES, int EPI, int MODE>
 __global__ __launch_bounds__(GNT) void gemm_persist_kernel(const DcGemmParams p, const int tile_group) {
@@ -950,13 +951,17 @@ int launch_glds(const DcGemmParams& p, hipStream_t stream) {
 // default 3 (bit 0: every 3x3 conv, bit 1: also the long-K (>= 1920) plain and temporal launches): 10-18 % faster than the
 // 8-wave kernel there (the chip holds a higher clock on v_mfma_f32_16x16x32_bf16); short-K launches stay on the
 // persistent kernels. Bit 3 of older plan values (9 / 11) is accepted and dropped.
-inline bool plan_valid(int plan) { return plan >= 0 && plan <= 15 && !(plan & 4); }
+// bit 4 (16): the ping-pong kernel (gemm_pp.h: 4-wave workgroups, two per CU) for the GEGLU projections with K <= 640 and
+// >= 1024 tiles; bit 5 (32): without the K limit (tests, A/B).
+constexpr int PLAN_DEFAULT = 3 | 16;
+constexpr int PLAN_MASK = 3 | 16 | 32;
+inline bool plan_valid(int plan) { return plan >= 0 && plan <= 63 && !(plan & 4); }
 std::atomic<int> g_gemm_plan{[] {
     const char* e = getenv("DC_GEMM_PLAN");
-    const int v = e ? atoi(e) : 3;
-    return plan_valid(v) ? (v & 3) : 3;
+    const int v = e ? atoi(e) : PLAN_DEFAULT;
+    return plan_valid(v) ? (v & PLAN_MASK) : PLAN_DEFAULT;
 }()};
-constexpr int PIPE_MIN_K = 1920;
+inline int pipe_min_k() { static const int v = [] { const char* e = getenv("DC_PIPE_MIN_K"); return e ? atoi(e) : 1920; }(); return v; }
 
 template <int MODE, int EPI>
 int launch_pipe_shape(const DcGemmParams& p, hipStream_t stream, GemmSplit sp, int gx, int gy) {
@@ -967,7 +972,7 @@ int launch_pipe_shape(const DcGemmParams& p, hipStream_t stream, GemmSplit sp, i
 
 inline bool pipe_ok(const DcGemmParams& p, int plan) {
     if (!(plan & 3) || (!(plan & 2) && p.mode != 1)) return false;
-    if (p.mode != 1 && p.K < PIPE_MIN_K) return false;
+    if (p.mode != 1 && p.K < pipe_min_k()) return false;
     if (p.flags & (DC_GEMM_GEGLU | DC_GEMM_OUT_F32)) return false;
     if (p.ups && !(p.mode == 1 && p.ups == 1 && p.stride == 1 && p.pad == 1 && p.OH == 2 * p.IH && p.OW == 2 * p.IW)) return false;
     if (p.N % 320 != 0 || p.n_pad < p.N || p.K % 64 != 0 || p.lda % 8 != 0 || ((uintptr_t)p.A % 16) != 0) return false;
@@ -1067,11 +1072,16 @@ int dc_gemm_conv_glds_try(const DcGemmParams& p, hipStream_t stream) {
                                    (!p.residual || ((p.ldr % 8 == 0) && ((uintptr_t)p.residual % 16 == 0))));
     // the plan is read ONCE per dispatch: the label (dc_note_variant) and the kernel always agree, whatever a concurrent
     // dc_gemm_set_plan does
-    const bool use_pipe = pipe_ok(p, g_gemm_plan.load(std::memory_order_relaxed));
+    const int plan = g_gemm_plan.load(std::memory_order_relaxed);
+    const bool use_pipe = pipe_ok(p, plan);
     const bool prefer_pipe = (force == 0) && use_pipe;
     if (persist && force == 0 && p.mode == 0 && epi16 && p.K <= persist_max_k() && !prefer_pipe) {
         // one workgroup per CU; needs at least 2 output tiles per workgroup to have anything to overlap
         static const int wide = [] { const char* e = getenv("DC_GEMM_PERSIST_WIDE"); return e ? atoi(e) : 1; }();
+        // ping-pong kernel: measured ahead of the 8-wave kernel at K = 640 (547-560 vs 577-584 us on [73728 x 640 -> 2 x 2560]), level
+        // with it at K = 1280, behind on the 18-row-panel level-3 launch (profiles/r04_pp_ab.txt): K <= 640 only
+        // (plan bit 5 lifts the K limit: tests and same-box A/B)
+        if (geglu && (plan & 16) && ((plan & 32) || p.K <= 640) && pp_ok(p) && tiles_m * (n_out / 64) >= 1024) return launch_pp<true, 0>(p, stream);
         if (geglu) {
             // each workgroup re-streams its A panel once per N tile: the wider tile halves that traffic
             if (wide && n_out % 128 == 0 && tiles_m * (n_out / 128) >= 512) return launch_persist<256, true>(p, stream, 256);
@@ -1152,5 +1162,5 @@ int dc_gemm_conv_glds_try(const DcGemmParams& p, hipStream_t stream) {
 
 extern "C" int dc_gemm_set_plan(int plan) {
     if (!plan_valid(plan)) return DC_ERR_ARG;
-    return g_gemm_plan.exchange(plan & 3, std::memory_order_relaxed);
+    return g_gemm_plan.exchange(plan & PLAN_MASK, std::memory_order_relaxed);
 }

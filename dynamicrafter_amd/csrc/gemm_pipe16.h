@@ -355,7 +355,7 @@ void gemm_pipe320x16_kernel(const DcGemmParams p, const GemmSplit sp) {
                     const float4 bv = *reinterpret_cast<const float4*>(p.bias + n);
                     v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
                 }
-                if (p.flags & DC_GEMM_GELU) { v.x = gelu_erf_f(v.x); v.y = gelu_erf_f(v.y); v.z = gelu_erf_f(v.z); v.w = gelu_erf_f(v.w); }
+                if (p.flags & DC_GEMM_GELU) { v.x = DC_GELU(v.x); v.y = DC_GELU(v.y); v.z = DC_GELU(v.z); v.w = DC_GELU(v.w); }
                 if (rv) {
                     const float4 r4 = *reinterpret_cast<const float4*>(rv + n);
                     v.x += r4.x; v.y += r4.y; v.z += r4.z; v.w += r4.w;

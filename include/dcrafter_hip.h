@@ -60,10 +60,11 @@ const char* dc_gemm_last_variant(void);
 
 /* Which kernels take the launches with 320-wide tiles. bit 0: the one-wave-per-SIMD kernel on v_mfma_f32_16x16x32_bf16
  * (gemm_pipe16.h: activations straight into registers, no barrier in the K loop) for the 3x3 convs, bit 1: also for plain /
- * temporal launches with K >= 1920. Default 3: the matrix pipe is power-managed on MI355X and holds a higher clock on the
- * 16x16x32 shape. 0 = the 8-wave LDS-DMA kernels everywhere. Bit 3 is accepted and ignored (it once chose between
+ * temporal launches with K >= 1920; bit 4 (16): the ping-pong kernel (gemm_pp.h: 4-wave workgroups, two per CU, whose epilogues
+ * overlap each other's K loops) for GEGLU projections with K <= 640, bit 5 (32): for any K. Default 19 (bits 0, 1, 4): the matrix
+ * pipe is power-managed on MI355X and holds a higher clock on the 16x16x32 shape. 0 = the 8-wave LDS-DMA kernels everywhere. Bit 3 is accepted and ignored (it once chose between
  * the two MFMA shapes of that kernel: plans 9 / 11 = 1 / 3); bit 2 is rejected (the 32x32x16 form and the LDS-window conv kernel
- * lost every measured shape and live in tools/experimental). Both plans give the same results to bf16 rounding and each is
+ * lost every measured shape and live in tools/experimental). All plans give the same results to bf16 rounding and each is
  * bit-reproducible. Process-wide (env DC_GEMM_PLAN sets the initial value, validated the same way). Returns the previous plan,
  * or DC_ERR_ARG. */
 int dc_gemm_set_plan(int plan);

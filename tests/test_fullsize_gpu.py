@@ -263,8 +263,11 @@ def test_unet_32x32_config1():
 
 # ---- multi-step parity at full width (VERDICT r3 weak 1 / missing 3): the drift of the bf16 residual stream over steps is a
 # full-width effect; the tiny-net trajectories cannot bound it. Tolerances = 1.5x the values measured on MI355X (printed).
-TRAJ256_TOL = {"eta0": (2.0e-2, 4.5e-2, 9.0e-2), "eta1": (2.0e-2, 4.5e-2, 9.0e-2)}     # x after steps 1 / 5 / 10 vs the REFERENCE
-TRAJ512_TOL = 6.0e-2                                                                  # x after each of 5 guided steps vs the oracle
+# measured (round 4): x after steps 1 / 5 / 10 vs the REFERENCE 1.77e-2 / 1.95e-2 / 1.95e-2 (eta 0), 2.37e-2 / 2.43e-2 / 2.42e-2
+# (eta 1): the error of the first step is NOT amplified over the trajectory at full width (the tiny nets' linear drift is not
+# what the 1.44 B-parameter model does), so no fp32 residual stream is needed
+TRAJ256_TOL = {"eta0": (2.6e-2, 2.9e-2, 2.9e-2), "eta1": (3.5e-2, 3.6e-2, 3.6e-2)}
+TRAJ512_TOL = 6.0e-2                              # x after each of 5 guided steps vs the oracle (provisional until measured)
 
 
 def test_trajectory_fullwidth_10_steps_vs_reference():

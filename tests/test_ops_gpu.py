@@ -725,6 +725,63 @@ def test_gemm_and_tconv_pipe_plan(ops, gemm_plan):
     test_tconv3_ragged_wide(ops)
 
 
+# ---- the ping-pong kernel (gemm_pp.h: 4-wave workgroups, two per CU, GEGLU formed in registers) behind plan bit 4 (16: default,
+# K <= 640) and bit 5 (32: any K)
+@pytest.mark.parametrize("gemm_plan", [51, 19, 3], indirect=True)
+@pytest.mark.parametrize("M,dim,inner", [
+    (73728, 640, 2560),        # level 1 of the 1024 config: 288 x 40 tiles, 10 K tiles
+    (18432, 1280, 5120),       # level 2: 72 x 80 tiles, 20 K tiles
+    (4608, 1280, 5120),        # level 3: 18 x 80 tiles
+    (16384 + 77, 192, 1024),   # ragged rows, 3 K tiles (K range shorter than the weight ring)
+    (32768, 128, 512),         # 2 K tiles
+])
+def test_gemm_geglu_pingpong(ops, gemm_plan, M, dim, inner):
+    g = torch.Generator(device=DEV).manual_seed(5)
+    x = torch.randn(M, dim, device=DEV, generator=g).to(torch.bfloat16)
+    w = (torch.randn(2 * inner, dim, device=DEV, generator=g) * dim ** -0.5)
+    b = torch.randn(2 * inner, device=DEV, generator=g) * 0.1
+    pw = ops.PackedWeight.linear(w.cpu(), b.cpu(), DEV)
+    big = torch.zeros(M, inner + 64, dtype=torch.bfloat16, device=DEV)            # strided output view (ldc > width)
+    outs = []
+    for _ in range(2):
+        out = big[:, 64:] if not outs else torch.empty(M, inner, dtype=torch.bfloat16, device=DEV)
+        ops.gemm(x, pw, out, geglu=True)
+        outs.append(out)
+    v = _variant(ops)
+    assert ("gemm_pp_kernel<geglu>" in v) == (gemm_plan == 51 or (gemm_plan == 19 and dim <= 640)), v
+    h = x.float() @ w.to(torch.bfloat16).float().t() + b
+    val, gate = h.chunk(2, dim=-1)
+    ref = val * F.gelu(gate)
+    assert rel_l2(outs[0], ref) < 4e-3
+    assert torch.equal(outs[0], outs[1])                                           # bitwise reproducible, any output stride
+    assert big[:, :64].abs().max().item() == 0
+    from dynamicrafter_amd import _hip
+    _hip.check_error_word("gemm_pp")
+
+
+def test_gelu_phi_error(ops):
+    """The GEMM epilogues' GELU is x * Phi(x) with a clamped degree-6 polynomial for Phi (csrc/dc_common.h: gelu_phi_f) instead
+    of erf: max |error| against torch's erf GELU <= 2.5e-4 over the whole range the kernel can see (stated 1.9e-4 + the bf16
+    rounding of the test's own output), exactly x / exactly 0 beyond |x| = 4. Measured through the GELU epilogue of dc_gemm_conv
+    with an identity weight: out = gelu(x)."""
+    K = 64
+    xs = torch.linspace(-12, 12, 256 * 1024, dtype=torch.float32)
+    x = torch.zeros(xs.numel() // K, K)
+    x[:] = xs.view(-1, K)
+    xb = bf(x)
+    pw = ops.PackedWeight.linear(torch.eye(K), torch.zeros(K), DEV)
+    out = torch.empty(x.shape[0], K, dtype=torch.float32, device=DEV)
+    ops.gemm(xb.to(DEV), pw, out, gelu=True)
+    ref = F.gelu(xb.double())
+    err = (out.double().cpu() - ref).abs()
+    print(f"\n[gelu_phi] max |gelu_phi - gelu_erf| = {err.max().item():.3e} at x = {xb.flatten()[err.argmax()].item():.3f}")
+    assert err.max().item() < 2.5e-4
+    far = xb.flatten().abs() > 4.0
+    o = out.cpu().flatten()
+    assert torch.equal(o[far & (xb.flatten() > 0)], xb.flatten()[far & (xb.flatten() > 0)].float())
+    assert o[far & (xb.flatten() < 0)].abs().max().item() == 0.0
+
+
 # ---- dispatch fuzz: random shapes across the tile / persistent / split-K decision boundaries. The checker is a
 # device-side fp32 matmul / conv (rocBLAS / MIOpen via torch) - CPU references of these sizes would take minutes.
 def _fuzz_cases():

@@ -20,7 +20,9 @@ SHAPES = [
     ("lin 1280x1280 L2", "lin", 18432, 1280, 1280),
     ("ffout 1280->320 L0", "lin", 294912, 1280, 320),
     ("geglu 320->2560 L0", "geglu", 294912, 320, 2560),
+    ("geglu 640->5120 L1", "geglu", 73728, 640, 5120),
     ("geglu 1280->10240 L2", "geglu", 18432, 1280, 10240),
+    ("geglu 1280->10240 L3", "geglu", 4608, 1280, 10240),
     ("conv3x3 320->320 72x128", "conv", (72, 128), 320, 320),
     ("conv3x3 640->640 36x64", "conv", (36, 64), 640, 640),
     ("conv3x3 1280->1280 18x32", "conv", (18, 32), 1280, 1280),
