@@ -38,8 +38,8 @@ UNET_TOL, UNET_COS = 3e-2, 0.9997
 STEP_TOL = 2.3e-2
 # classifier-free guidance at scale 7.5 amplifies the branch errors (g = 7.5 e_c - 6.5 e_u): measured 4.5e-2 / 4.4e-2 on the guided
 # output at 16x40x64 / 16x32x32 (3x the per-branch 1.5e-2: e_c - e_u is 0.33-0.40 of |e_c| here and carries 4.8e-2), and
-# 2.8e-4 / 5.5e-3 on x_prev of a full step; bounds = 2x measured
-GUIDED_TOL, GUIDED_STEP_TOL = 9e-2, 1.1e-2
+# 2.8e-4 / 5.5e-3 on x_prev of a full step; bounds = 1.5x measured for the guided output (4.35e-2 - 4.43e-2 at the three sizes), 2x for x_prev
+GUIDED_TOL, GUIDED_STEP_TOL = 6.6e-2, 1.1e-2
 GUIDED_STEP_TOL_T999 = 2.3e-2     # first executed step (t = 999, zero terminal SNR): x_prev IS the guided, rescaled v-prediction
                                   # (measured 1.12e-2 at 16x72x128 with both branches from both sides; guided output 4.3e-2)
 AE_MOM_TOL, AE_Z_TOL, AE_DEC_TOL = 3e-2, 1e-2, 2.7e-2
@@ -267,7 +267,9 @@ def test_unet_32x32_config1():
 # (eta 1): the error of the first step is NOT amplified over the trajectory at full width (the tiny nets' linear drift is not
 # what the 1.44 B-parameter model does), so no fp32 residual stream is needed
 TRAJ256_TOL = {"eta0": (2.6e-2, 2.9e-2, 2.9e-2), "eta1": (3.5e-2, 3.6e-2, 3.6e-2)}
-TRAJ512_TOL = 6.0e-2                              # x after each of 5 guided steps vs the oracle (provisional until measured)
+# 512 config, 5 guided steps (S = 5: each step spans 200 timesteps), x vs the oracle after every step: 4.1e-3 / 9.9e-3 / 1.66e-2 /
+# 2.51e-2 / 2.88e-2 (pred_x0: 4.5e-2 at the first step, where it IS the guided prediction, falling to 2.9e-2): bound = 1.5x the last
+TRAJ512_TOL = 4.4e-2
 
 
 def test_trajectory_fullwidth_10_steps_vs_reference():

@@ -255,7 +255,7 @@ def test_flash_attn_long_self_running_max_jumps(ops, flash_mode, spikes, L):
     assert rel_l2(o, ref) < 6e-3
 
 
-@pytest.mark.parametrize("flash_mode", [(0, 8.0), (4, 8.0)], indirect=True)
+@pytest.mark.parametrize("flash_mode", [(0, 8.0), (2, 8.0)], indirect=True)
 @pytest.mark.parametrize("L", [512, 768])
 @pytest.mark.parametrize("pos", [3, 33, 100, 300, 511])
 def test_flash_attn_long_self_fallback_to_tracking_pass(ops, flash_mode, pos, L):
@@ -284,7 +284,7 @@ def test_flash_attn_long_self_fallback_to_tracking_pass(ops, flash_mode, pos, L)
     assert rel_l2(o, ref) < 6e-3
 
 
-@pytest.mark.parametrize("flash_mode", [(0, 8.0), (4, 8.0)], indirect=True)
+@pytest.mark.parametrize("flash_mode", [(0, 8.0), (2, 8.0)], indirect=True)
 def test_flash_attn_long_self_all_scores_far_below_zero(ops, flash_mode):
     """Every score of some rows below -100 in exp2 units (q and all keys anti-aligned and large): the default pass's row sums
     underflow there and the fallback must produce the ordinary softmax."""
