@@ -102,6 +102,10 @@ __global__ void gn_partial_kernel(const bf16_t* __restrict__ x, int ldx, int C, 
 // grid (groups, n_inst), one wave each: reduce the chunk partials of one (instance, group) in a fixed order (lane-strided
 // sums, then a fixed shuffle tree) -> (mean, rstd). One workgroup per instance took 12 us on the 5-D norms (2 instances
 // x 1024 chunks); spread over groups it is launch-latency-bound.
+// (Round 4, measured and reverted: the same reduction inside gn_apply_kernel for instances with <= 64 chunks - every workgroup
+// of the apply pass reduces its instance's 32 groups itself, one launch fewer per norm. The reduction is a latency chain (loads,
+// six dependent Chan merges with a reciprocal each) and 8-11 groups per wave run it back to back: +7 us per norm instead of -5;
+// the step went 125.3 -> 126.1 ms at 1024, 23.5 -> 24.2 at 256, 42.0 -> 42.8 at 512, same box.)
 __global__ __launch_bounds__(64) void gn_finalize_kernel(const float2* __restrict__ partial, int chunks, int groups,
                                                          int rows_per_inst, int rows_per_chunk, int cpg, float eps,
                                                          float2* __restrict__ stats) {
