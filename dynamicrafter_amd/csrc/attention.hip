@@ -14,6 +14,7 @@
 #include "dc_common.h"
 #include "dcrafter_hip.h"
 #include <stdlib.h>
+#include <type_traits>
 
 namespace {
 
@@ -303,6 +304,184 @@ __global__ __launch_bounds__(256, 2) void flash_attn_d64_kernel(
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// Text + image cross-attention with the keys RESIDENT: both key / value sets of a (batch item, head) - 77 text and 16 image
+// tokens in DynamiCrafter - are staged into LDS once and the workgroup then walks up to XA_QT_MAX query tiles of 128 rows under them.
+// Why: flash_attn_d64_kernel<1, true> stages the sets tile by tile per 128 query rows - three global -> register -> LDS ->
+// barrier round trips (text 2 tiles, image 1) whose latency nothing hides (the arithmetic between them is ~30 MFMAs), 24 KB of
+// K / V through the L2 -> CU path for 32 KB of q and o - and ran the level-0 launches at 1.9 TB/s of q + o. Here a query tile
+// costs its own bytes only, the next tile's q is requested before the current one is computed, and there is no barrier in the
+// loop. All keys of a set are visible at once, so the softmax is a plain two-pass one (max, then exp and sum): no running state.
+// 64 < Lk <= 96, Lk2 <= 32 (dc_cross_attn_dual_d64 keeps the general kernel for anything else). Same fragment scheme as above:
+// S^T = K (cQ)^T so a lane owns a query row; the packed S^T accumulator is the B operand of O^T += V^T P^T; V^T via tr reads.
+constexpr int XA_QT_MAX = 8;                                // query tiles of 128 rows per workgroup: chosen per launch (below)
+constexpr int XA_K1 = 0, XA_V1 = 96 * 128, XA_K2 = XA_V1 + 96 * V_LD, XA_V2 = XA_K2 + 32 * 128, XA_LDS = XA_V2 + 32 * V_LD;
+
+__global__ __launch_bounds__(256, 2) void cross_attn_resident_kernel(
+    const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v, const bf16_t* __restrict__ k2,
+    const bf16_t* __restrict__ v2, bf16_t* __restrict__ o, int ldq, int ldkv, int ldo, int heads, int Lq, int Lk, int Lk2,
+    int64_t q_bstride, int64_t kv_bstride, float c /* scale*log2(e) */, float acc_scale, int q_groups, int qt) {
+    __shared__ __attribute__((aligned(16))) char smem[XA_LDS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fr = lane & 31, fh = lane >> 5;
+    const int id = xcd_remap(blockIdx.x, gridDim.x);
+    const int qg = id % q_groups;
+    const int bh = id / q_groups;
+    const int head = bh % heads;
+    const int b = bh / heads;
+    const bf16_t* qb = q + (size_t)b * q_bstride * ldq + head * 64;
+    bf16_t* ob = o + (size_t)b * q_bstride * ldo + head * 64;
+
+    // ---- both key / value sets -> LDS, once (rows past a set's length repeat its last row: finite data, masked below)
+    {
+        const int chunk = tid & 7, srow = tid >> 3;
+        const bf16_t* kb1 = k + (size_t)b * kv_bstride * ldkv + head * 64;
+        const bf16_t* vb1 = v + (size_t)b * kv_bstride * ldkv + head * 64;
+        const bf16_t* kb2 = k2 + (size_t)b * kv_bstride * ldkv + head * 64;
+        const bf16_t* vb2 = v2 + (size_t)b * kv_bstride * ldkv + head * 64;
+        u32x4_t kr[4], vr[4];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            int j = srow + 32 * i;
+            j = j < Lk ? j : Lk - 1;
+            kr[i] = *reinterpret_cast<const u32x4_t*>(kb1 + (size_t)j * ldkv + chunk * 8);
+            vr[i] = *reinterpret_cast<const u32x4_t*>(vb1 + (size_t)j * ldkv + chunk * 8);
+        }
+        {
+            const int j = srow < Lk2 ? srow : Lk2 - 1;
+            kr[3] = *reinterpret_cast<const u32x4_t*>(kb2 + (size_t)j * ldkv + chunk * 8);
+            vr[3] = *reinterpret_cast<const u32x4_t*>(vb2 + (size_t)j * ldkv + chunk * 8);
+        }
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int r = srow + 32 * i;
+            *reinterpret_cast<u32x4_t*>(smem + XA_K1 + k_lds_off(r, chunk)) = kr[i];
+            *reinterpret_cast<u32x4_t*>(smem + XA_V1 + r * V_LD + chunk * 16) = vr[i];
+        }
+        *reinterpret_cast<u32x4_t*>(smem + XA_K2 + k_lds_off(srow, chunk)) = kr[3];
+        *reinterpret_cast<u32x4_t*>(smem + XA_V2 + srow * V_LD + chunk * 16) = vr[3];
+    }
+    const int li = lane & 15;
+    const int tr_off = (li >> 2) * V_LD + (((lane >> 4) & 1) * 16 + (li & 3) * 4) * 2;
+
+    const int row0 = qg * (qt * 128) + wave * 32 + fr;              // this lane's query row in tile 0
+    auto load_q = [&](int tile, u32x4_t (&raw)[4]) __attribute__((always_inline)) {
+        int qr = row0 + tile * 128;
+        qr = qr < Lq ? qr : Lq - 1;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) raw[kk] = *reinterpret_cast<const u32x4_t*>(qb + (size_t)qr * ldq + kk * 16 + fh * 8);
+    };
+    u32x4_t qraw[4];
+    load_q(0, qraw);
+    __syncthreads();                                                // the only barrier: K / V are in place
+
+    // scores of one set: NB key blocks of 32; softmax in place (s -> p), returns the row sum
+    auto scores = [&](const char* sk, int nkeys, auto NB_, f32x16_t (&s)[3], const bf16x8_t (&qf)[4]) __attribute__((always_inline)) -> float {
+        constexpr int NB = decltype(NB_)::value;
+#pragma unroll
+        for (int jb = 0; jb < NB; ++jb) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[jb][r] = 0.f;
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                const bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(sk + k_lds_off(jb * 32 + fr, kk * 2 + fh));
+                s[jb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[kk], s[jb], 0, 0, 0);
+            }
+        }
+        // keys past the set's length (only the last block can hold any)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int j = (NB - 1) * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+            if (j >= nkeys) s[NB - 1][r] = -1e30f;
+        }
+        float mx = s[0][0];
+#pragma unroll
+        for (int jb = 0; jb < NB; ++jb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[jb][r]);
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));                     // the partner lane holds the row's other keys
+        float sum = 0.f;
+#pragma unroll
+        for (int jb = 0; jb < NB; ++jb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float pv = __builtin_amdgcn_exp2f(s[jb][r] - mx);
+                s[jb][r] = pv;
+                sum += pv;
+            }
+        return sum + __shfl_xor(sum, 32, 64);
+    };
+    // O^T += V^T P^T over the NB key blocks of a set
+    auto pv_mma = [&](const char* sv, auto NB_, const f32x16_t (&s)[3], f32x16_t (&oacc)[2]) __attribute__((always_inline)) {
+        constexpr int NB = decltype(NB_)::value;
+#pragma unroll
+        for (int jb = 0; jb < NB; ++jb)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const int jbase = jb * 32 + 16 * ks + 4 * fh;
+                u32x4_t pw;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) pw[e] = pack_bf2(s[jb][8 * ks + 2 * e], s[jb][8 * ks + 2 * e + 1]);
+                const bf16x8_t pf = __builtin_bit_cast(bf16x8_t, pw);
+#pragma unroll
+                for (int db = 0; db < 2; ++db) {
+                    const char* vp = sv + jbase * V_LD + db * 64 + tr_off;
+                    const bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_bf16x4_t*)(vp));
+                    const bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_bf16x4_t*)(vp + 8 * V_LD));
+                    bf16x8_t vf;
+                    vf[0] = lo[0]; vf[1] = lo[1]; vf[2] = lo[2]; vf[3] = lo[3];
+                    vf[4] = hi[0]; vf[5] = hi[1]; vf[6] = hi[2]; vf[7] = hi[3];
+                    oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, oacc[db], 0, 0, 0);
+                }
+            }
+    };
+
+    const int n_tiles = qt;
+#pragma unroll 1
+    for (int tile = 0; tile < n_tiles; ++tile) {
+        const int qrow = row0 + tile * 128;
+        if (qg * (qt * 128) + tile * 128 >= Lq) break;              // workgroup-uniform: no rows left in this group
+        // Q fragments (B operand), pre-multiplied by scale*log2(e): the scores leave the MFMA in exp2 units
+        bf16x8_t qf[4];
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            u32x4_t sc;
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                sc[e] = pack_bf2(__uint_as_float(qraw[kk][e] << 16) * c, __uint_as_float(qraw[kk][e] & 0xffff0000u) * c);
+            qf[kk] = __builtin_bit_cast(bf16x8_t, sc);
+        }
+        if (tile + 1 < n_tiles) load_q(tile + 1, qraw);             // next tile's rows (clamped): in flight under this tile
+        f32x16_t s[3], o1[2], o2[2];
+#pragma unroll
+        for (int d = 0; d < 2; ++d)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { o1[d][r] = 0.f; o2[d][r] = 0.f; }
+        const float l1 = scores(smem + XA_K1, Lk, std::integral_constant<int, 3>{}, s, qf);
+        pv_mma(smem + XA_V1, std::integral_constant<int, 3>{}, s, o1);
+        const float l2 = scores(smem + XA_K2, Lk2, std::integral_constant<int, 1>{}, s, qf);
+        pv_mma(smem + XA_V2, std::integral_constant<int, 1>{}, s, o2);
+        const float w1 = 1.0f / l1, w2 = acc_scale / l2;
+        // store: a row's channels 8 qd .. 8 qd + 7 are split over its two lanes; one v_permlane32_swap per dword between the
+        // groups qd and qd + 1 gives each lane 16 contiguous bytes
+        bf16_t* orow = ob + (size_t)(qrow < Lq ? qrow : Lq - 1) * ldo;
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int qd = 0; qd < 4; qd += 2) {
+                float f[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) f[e] = w1 * o1[db][4 * qd + e] + w2 * o2[db][4 * qd + e];
+                const unsigned a0 = pack_bf2(f[0], f[1]), a1 = pack_bf2(f[2], f[3]);
+                const unsigned b0 = pack_bf2(f[4], f[5]), b1 = pack_bf2(f[6], f[7]);
+                const auto r0 = __builtin_amdgcn_permlane32_swap(a0, b0, false, false);
+                const auto r1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);
+                u32x4_t pk = {r0[0], r1[0], r0[1], r1[1]};
+                if (qrow < Lq) *reinterpret_cast<u32x4_t*>(orow + db * 32 + 8 * (qd + fh)) = pk;
+            }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // Temporal attention: one wave per (b, p, head). T <= 16 (rows beyond T are masked).
 //   S^T[t'][t] = K Q^T            : v_mfma_f32_16x16x32_bf16 x2 (d = 64), fragments straight from global
 //   softmax over t' (4 regs x 4 lane groups)
@@ -438,6 +617,28 @@ extern "C" int dc_cross_attn_dual_d64(const uint16_t* q, const uint16_t* k, cons
     if (batch <= 0 || heads <= 0 || Lq <= 0 || Lk <= 0 || Lk2 <= 0) return DC_ERR_SHAPE;
     if (ldq % 8 || ldkv % 8 || ldo % 8 || (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)k2 | (uintptr_t)v2 | (uintptr_t)o) & 15)) return DC_ERR_SHAPE;   // 16-byte loads and stores
     const float c = scale * 1.4426950408889634f;
+    // the sets of DynamiCrafter (77 text + 16 image tokens) stay resident in LDS under XA_QT query tiles per workgroup;
+    // DC_XATTN_RESIDENT=0 keeps the tile-by-tile kernel (same-box A/B)
+    static const bool resident = [] { const char* e = getenv("DC_XATTN_RESIDENT"); return !(e && e[0] == '0'); }();
+    if (resident && Lk > 64 && Lk <= 96 && Lk2 <= 32 && Lq >= 512) {
+        // tiles per workgroup: the value whose grid wastes the least of its last round of 3 workgroups x 256 CUs (ties: the
+        // larger, which amortises the staging over more rows)
+        const int tiles = (Lq + 127) / 128;
+        int qt = 1;
+        long long best = -1;
+        for (int t = 1; t <= XA_QT_MAX; ++t) {
+            const long long wgs = (long long)((tiles + t - 1) / t) * heads * batch;
+            const long long cost = ((wgs + 767) / 768) * t;
+            if (best < 0 || cost <= best) { best = cost; qt = t; }
+        }
+        const int q_groups = (tiles + qt - 1) / qt;
+        const long long nwg_r = (long long)q_groups * heads * batch;
+        if (nwg_r > 0x7fffffffLL) return DC_ERR_SHAPE;
+        hipLaunchKernelGGL(cross_attn_resident_kernel, dim3((unsigned)nwg_r), dim3(256), 0, stream, q, k, v, k2, v2, o, ldq, ldkv, ldo,
+                           heads, Lq, Lk, Lk2, q_bstride, kv_bstride, c, scale2, q_groups, qt);
+        DC_CHECK_LAUNCH();
+        return 0;
+    }
     const int q_tiles = (Lq + FA_BQ - 1) / FA_BQ;
     const long long nwg = (long long)q_tiles * heads * batch;
     if (nwg > 0x7fffffffLL) return DC_ERR_SHAPE;

@@ -64,13 +64,20 @@ void gemm_pipe320x16_kernel(const DcGemmParams p, const GemmSplit sp) {
     if (MODE == 1) bias = (long long)(p.pad * p.IW + p.pad) * lda2;
     if (MODE == 2) bias = (long long)p.HW * lda2;
     if (MODE == 3) bias = (long long)(p.IW + 1) * lda2;
+#ifdef GP_DBG_QUAD_ROWS      // tool build (results wrong): the four lanes of a quad read 64 contiguous bytes of ONE row (addresses and
+                             // tap masks of that row) - what the activation loads would cost the texture-address path if the fragment
+                             // layout allowed coalescing
+    const int lr_a = lr & ~3, lq_a = lane & 3;
+#else
+    const int lr_a = lr, lq_a = lq;
+#endif
 #pragma unroll
     for (int rb = 0; rb < 4; ++rb) {
-        const int m = m0 + wave * 64 + rb * 16 + lr;
+        const int m = m0 + wave * 64 + rb * 16 + lr_a;
         const bool ok = m < p.M;
         const int mm = ok ? m : 0;
         if (MODE == 0) {
-            rowoff[rb] = (unsigned)mm * lda2 + lq * 16;
+            rowoff[rb] = (unsigned)mm * lda2 + lq_a * 16;
             mask[rb] = ok ? 1 : 0;
         } else if (MODE == 1) {
             const int ohw = p.OH * p.OW;
@@ -86,7 +93,7 @@ void gemm_pipe320x16_kernel(const DcGemmParams p, const GemmSplit sp) {
                 if (ok && iy >= 0 && iy < p.IH && ix >= 0 && ix < p.IW) mk |= 1 << t;
             }
             mask[rb] = mk;
-            rowoff[rb] = (unsigned)(((n * p.IH + iy0 + p.pad) * p.IW + ix0 + p.pad)) * lda2 + lq * 16;
+            rowoff[rb] = (unsigned)(((n * p.IH + iy0 + p.pad) * p.IW + ix0 + p.pad)) * lda2 + lq_a * 16;
         } else if (MODE == 3) {
             // nearest x2 upsampling fused into the conv (stride 1, pad 1): tap (dy, dx) of output pixel (oy, ox) reads input pixel
             // ((oy + dy - 1) >> 1, (ox + dx - 1) >> 1) = centre (oy >> 1, ox >> 1) + (ry, rx), ry = {py - 1, 0, py}[dy] with py = oy & 1
@@ -103,7 +110,7 @@ void gemm_pipe320x16_kernel(const DcGemmParams p, const GemmSplit sp) {
                 if (ok && uy >= 0 && uy < p.OH && ux >= 0 && ux < p.OW) mk |= 1 << t;
             }
             mask[rb] = mk | ((oy & 1) << 9) | ((ox & 1) << 10);
-            rowoff[rb] = (unsigned)(((n * p.IH + (oy >> 1) + 1) * p.IW + (ox >> 1) + 1)) * lda2 + lq * 16;
+            rowoff[rb] = (unsigned)(((n * p.IH + (oy >> 1) + 1) * p.IW + (ox >> 1) + 1)) * lda2 + lq_a * 16;
         } else {
             const int frame = (mm / p.HW) % p.T;
             int mk = 0;
@@ -113,7 +120,7 @@ void gemm_pipe320x16_kernel(const DcGemmParams p, const GemmSplit sp) {
                 if (ok && tt >= 0 && tt < p.T) mk |= 1 << t;
             }
             mask[rb] = mk;
-            rowoff[rb] = (unsigned)mm * lda2 + lq * 16;
+            rowoff[rb] = (unsigned)mm * lda2 + lq_a * 16;
         }
     }
     gp_i32x4_t ars;

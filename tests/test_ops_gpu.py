@@ -880,7 +880,11 @@ def test_clip_preprocess_patchify_embed_vs_oracle(ops):
     assert torch.equal(out.cpu(), ref)
 
 
-@pytest.mark.parametrize("B,heads,Lq,nt,ni,s2", [(3, 5, 300, 77, 16, 1.0), (2, 2, 70, 77, 16, 1.7), (1, 20, 144, 5, 3, 0.4)])
+@pytest.mark.parametrize("B,heads,Lq,nt,ni,s2", [(3, 5, 300, 77, 16, 1.0), (2, 2, 70, 77, 16, 1.7), (1, 20, 144, 5, 3, 0.4),
+                                                 # Lq >= 512, 64 < Lk <= 96, Lk2 <= 32: the keys-resident kernel (several query tiles per
+                                                 # workgroup under one staging of both sets): level 0 / 1 / 2 of the 1024 config, ragged rows
+                                                 (4, 5, 9216, 77, 16, 1.0), (3, 10, 2304, 77, 16, 0.7), (2, 20, 576, 77, 16, 1.3),
+                                                 (2, 3, 1000, 90, 32, 0.5), (1, 2, 640, 65, 1, 1.0)])
 def test_cross_attn_dual_vs_torch(ops, B, heads, Lq, nt, ni, s2):
     """Text + image cross-attention with separate softmaxes in one launch (attention.py:128-142) vs fp32 torch, and vs the
     two-launch form (text pass, then accumulate the image pass)."""
