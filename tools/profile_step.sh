@@ -4,7 +4,7 @@
 #      (MI355X_MICROARCH.md, HBM section: the two counters do not fit one pass)  -> per-kernel-family traffic table
 #   3. tools/traffic_table.py joins both with the algorithmic bytes of ops.Tracer (bench line's per_kernel_eager_step)
 # Output under gpurun_out/<tag>/; copy the summaries you keep into profiles/.
-TAG=${1:-r03}
+TAG=${1:-r04}
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/$TAG

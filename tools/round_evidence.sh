@@ -5,7 +5,7 @@
 #   tools/profile_step.sh         rocprofv3 kernel stats + PMC traffic table
 #   tools/pmc_one_gemm.sh         PMC counters of single kernels: flash attention 32x5x9216, the fused level-0 kernels (one_fused.py)
 # optional second argument: which part (bench | prof | pmc | all): gpurun limits one call to 20 minutes
-TAG=${1:-r03}
+TAG=${1:-r04}
 PART=${2:-all}
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/$TAG
@@ -32,6 +32,11 @@ PMC_SCRIPT=one_flash.py bash tools/pmc_one_gemm.sh flash 32 5 9216 9216 > $O/pmc
 # the level-1 skip-connection conv [73728 x 640 x 17280] on the default plan (gemm_pipe320x16_kernel) and on the 8-wave kernels
 bash tools/pmc_one_gemm.sh conv16 conv 1920 640 36 64 > $O/pmc_conv16.log 2>&1; python tools/pmc_summary.py $R/gpurun_out/pmc_conv16 > $O/${TAG}_pmc_conv16.txt 2>&1; tail -12 $O/${TAG}_pmc_conv16.txt
 DC_GEMM_PLAN=0 bash tools/pmc_one_gemm.sh conv8w conv 1920 640 36 64 > $O/pmc_conv8w.log 2>&1; python tools/pmc_summary.py $R/gpurun_out/pmc_conv8w > $O/${TAG}_pmc_conv8w.txt 2>&1; tail -12 $O/${TAG}_pmc_conv8w.txt
+# the GEGLU projections (level 1: ping-pong kernel, level 2: persistent 8-wave kernel) and the level-2 linear (gemm_persist<128>)
+bash tools/pmc_one_gemm.sh geglu_l1 geglu 640 5120 36 64 > $O/pmc_geglu_l1.log 2>&1; python tools/pmc_summary.py $R/gpurun_out/pmc_geglu_l1 > $O/${TAG}_pmc_geglu_l1.txt 2>&1; tail -4 $O/${TAG}_pmc_geglu_l1.txt
+bash tools/pmc_one_gemm.sh geglu_l2 geglu 1280 10240 18 32 > $O/pmc_geglu_l2.log 2>&1; python tools/pmc_summary.py $R/gpurun_out/pmc_geglu_l2 > $O/${TAG}_pmc_geglu_l2.txt 2>&1; tail -4 $O/${TAG}_pmc_geglu_l2.txt
+bash tools/pmc_one_gemm.sh lin1280 lin 1280 1280 18 32 > $O/pmc_lin1280.log 2>&1; python tools/pmc_summary.py $R/gpurun_out/pmc_lin1280 > $O/${TAG}_pmc_persist128.txt 2>&1; tail -4 $O/${TAG}_pmc_persist128.txt
+PMC_SCRIPT=one_xattn.py bash tools/pmc_one_gemm.sh xattn > $O/pmc_xattn.log 2>&1; python tools/pmc_summary.py $R/gpurun_out/pmc_xattn > $O/${TAG}_pmc_xattn.txt 2>&1; tail -4 $O/${TAG}_pmc_xattn.txt
 for k in ff tconv lnlin linres; do
   PMC_SCRIPT=one_fused.py bash tools/pmc_one_gemm.sh $k $k > $O/pmc_$k.log 2>&1; python tools/pmc_summary.py $R/gpurun_out/pmc_$k > $O/${TAG}_pmc_$k.txt 2>&1; tail -8 $O/${TAG}_pmc_$k.txt
 done
