@@ -11,6 +11,7 @@
 //   attention.py:265,331 (eps 1e-6), AE Normalize ae_modules.py:15-16 (eps 1e-6) + swish :10-12.
 #include "dc_common.h"
 #include "dcrafter_hip.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -102,10 +103,6 @@ __global__ void gn_partial_kernel(const bf16_t* __restrict__ x, int ldx, int C, 
 // grid (groups, n_inst), one wave each: reduce the chunk partials of one (instance, group) in a fixed order (lane-strided
 // sums, then a fixed shuffle tree) -> (mean, rstd). One workgroup per instance took 12 us on the 5-D norms (2 instances
 // x 1024 chunks); spread over groups it is launch-latency-bound.
-// (Round 4, measured and reverted: the same reduction inside gn_apply_kernel for instances with <= 64 chunks - every workgroup
-// of the apply pass reduces its instance's 32 groups itself, one launch fewer per norm. The reduction is a latency chain (loads,
-// six dependent Chan merges with a reciprocal each) and 8-11 groups per wave run it back to back: +7 us per norm instead of -5;
-// the step went 125.3 -> 126.1 ms at 1024, 23.5 -> 24.2 at 256, 42.0 -> 42.8 at 512, same box.)
 __global__ __launch_bounds__(64) void gn_finalize_kernel(const float2* __restrict__ partial, int chunks, int groups,
                                                          int rows_per_inst, int rows_per_chunk, int cpg, float eps,
                                                          float2* __restrict__ stats) {
@@ -143,11 +140,63 @@ __global__ __launch_bounds__(64) void gn_finalize_kernel(const float2* __restric
     }
 }
 
+// FIN: the (mean, rstd) of the instance's groups are reduced from the chunk partials HERE instead of by gn_finalize_kernel - one
+// launch (5.6 us + a kernel boundary) less per norm. Round 4 first tried this with gn_finalize_kernel's own layout (a wave per
+// group, lanes = chunks): 8-11 latency chains back to back per wave, +7 us per workgroup, slower than the launch. This layout puts
+// EIGHT lanes on a group (thread t: group t / 8, chunks t % 8, + 8, ...): 32 groups in one pass of 256 threads, each lane a
+// serial chain of chunks / 8 Chan merges and three xor-shuffle merges - one L2 round trip and ~11 dependent merges per
+// workgroup. Fixed order: deterministic, but not the bits of gn_finalize_kernel (the two never feed the same consumer).
+template <bool FIN>
 __global__ void gn_apply_kernel(const bf16_t* __restrict__ x, int ldx, bf16_t* __restrict__ y, int ldy,
                                 const float* __restrict__ gamma, const float* __restrict__ beta, int C, int groups,
                                 int rows_per_inst, int rows_per_chunk, int vecs, int rpp, int silu,
-                                const float2* __restrict__ stats) {
+                                const float2* __restrict__ stats, int chunks, float eps) {
     const int inst = blockIdx.y, chunk = blockIdx.x;
+    __shared__ float2 st_s[64];
+    if constexpr (FIN) {
+        const int t = threadIdx.x, sub = t & 7;
+        const int gpp = (int)blockDim.x >> 3;                    // groups per pass (blockDim.x % 8 == 0: vecs * rpp, vecs = C / 8, C % 64 == 0 checked by the host)
+        const float cpg = (float)(C / groups);
+        for (int g0 = 0; g0 < groups; g0 += gpp) {
+            const int g = g0 + (t >> 3);
+            float n = 0.f, mean = 0.f, m2 = 0.f;
+            if (g < groups) {
+                for (int c = sub; c < chunks; c += 8) {
+                    const float2 p = stats[((size_t)inst * chunks + c) * groups + g];
+                    int rows = rows_per_inst - c * rows_per_chunk;
+                    if (rows > rows_per_chunk) rows = rows_per_chunk;
+                    const float nb = (float)rows * cpg;
+                    const float nn = n + nb;
+                    const float w = nb * __builtin_amdgcn_rcpf(nn);
+                    const float delta = p.x - mean;
+                    mean += delta * w;
+                    m2 += p.y + delta * delta * (n * w);
+                    n = nn;
+                }
+            }
+#pragma unroll
+            for (int o = 1; o < 8; o <<= 1) {
+                const float nb = __shfl_xor(n, o, 64), mb = __shfl_xor(mean, o, 64), qb = __shfl_xor(m2, o, 64);
+                const float nn = n + nb;
+                if (nn > 0.f) {
+                    // symmetric form: both partners of a pair compute the same merged (n, mean, m2) bit for bit
+                    const float lo_n = (sub & o) ? nb : n, lo_m = (sub & o) ? mb : mean, lo_q = (sub & o) ? qb : m2;
+                    const float hi_n = (sub & o) ? n : nb, hi_m = (sub & o) ? mean : mb, hi_q = (sub & o) ? m2 : qb;
+                    const float w = hi_n * __builtin_amdgcn_rcpf(nn);
+                    const float delta = hi_m - lo_m;
+                    mean = lo_m + delta * w;
+                    m2 = lo_q + hi_q + delta * delta * (lo_n * w);
+                    n = nn;
+                }
+            }
+            if (g < groups && sub == 0) {
+                float var = m2 / n;
+                if (var < 0.f) var = 0.f;
+                st_s[g] = make_float2(mean, rsqrtf(var + eps));
+            }
+        }
+        __syncthreads();
+    }
     const int v = threadIdx.x % vecs;
     const int ro = threadIdx.x / vecs;
     const int r_begin = chunk * rows_per_chunk;
@@ -158,7 +207,7 @@ __global__ void gn_apply_kernel(const bf16_t* __restrict__ x, int ldx, bf16_t* _
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
         const int c = v * 8 + e;
-        const float2 st = stats[(size_t)inst * groups + c / cpg];
+        const float2 st = FIN ? st_s[c / cpg] : stats[(size_t)inst * groups + c / cpg];
         const float g = gamma[c] * st.y;
         sc[e] = g;
         sh[e] = beta[c] - st.x * g;
@@ -284,11 +333,20 @@ extern "C" int dc_groupnorm(const uint16_t* x, int ldx, uint16_t* y, int ldy, co
     hipLaunchKernelGGL(gn_partial_kernel, dim3(g.chunks, n_inst), dim3(threads), lds, stream, x, ldx, C, groups,
                        rows_per_inst, g.rows_per_chunk, g.chunks, vecs, rpp, partial);
     DC_CHECK_LAUNCH();
+    // few chunks per instance (the 4-D norms of the UNet: 32 frames x 64 chunks): the apply pass reduces the partials itself
+    // (gn_apply_kernel<true>); DC_GN_FUSE_FINALIZE=0 keeps the separate launch (same-box A/B)
+    static const bool fuse_fin = [] { const char* e = getenv("DC_GN_FUSE_FINALIZE"); return !(e && e[0] == '0'); }();
+    if (fuse_fin && g.chunks <= 64 && threads % 8 == 0) {
+        hipLaunchKernelGGL(gn_apply_kernel<true>, dim3(g.chunks, n_inst), dim3(threads), 0, stream, x, ldx, y, ldy, gamma, beta,
+                           C, groups, rows_per_inst, g.rows_per_chunk, vecs, rpp, silu, (const float2*)partial, g.chunks, eps);
+        DC_CHECK_LAUNCH();
+        return 0;
+    }
     hipLaunchKernelGGL(gn_finalize_kernel, dim3(groups, n_inst), dim3(64), 0, stream, partial, g.chunks, groups, rows_per_inst,
                        g.rows_per_chunk, C / groups, eps, stats);
     DC_CHECK_LAUNCH();
-    hipLaunchKernelGGL(gn_apply_kernel, dim3(g.chunks, n_inst), dim3(threads), 0, stream, x, ldx, y, ldy, gamma, beta,
-                       C, groups, rows_per_inst, g.rows_per_chunk, vecs, rpp, silu, stats);
+    hipLaunchKernelGGL(gn_apply_kernel<false>, dim3(g.chunks, n_inst), dim3(threads), 0, stream, x, ldx, y, ldy, gamma, beta,
+                       C, groups, rows_per_inst, g.rows_per_chunk, vecs, rpp, silu, (const float2*)stats, g.chunks, eps);
     DC_CHECK_LAUNCH();
     return 0;
 }
