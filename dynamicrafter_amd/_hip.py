@@ -71,6 +71,7 @@ SIGNATURES = {
     "dc_pack_latent": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "dc_nchw_to_rows": (_I, [_P, _P, _I, _I, _I, _I, _F, _P]),
     "dc_rows_to_nchw": (_I, [_P, _I, _I, _P, _I, _I, _I, _F, _P]),
+    "dc_im2col3x3_c8": (_I, [_P, _I, _P, _I, _I, _I, _I, _P]),
     "dc_copy2d": (_I, [_P, _I, _P, _I, _I, _I, _P]),
     "dc_build_context": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
     "dc_softmax_rows": (_I, [_P, _I, _P, _I, _I, _I, _P]),

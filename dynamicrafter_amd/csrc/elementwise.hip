@@ -136,6 +136,29 @@ __global__ void copy2d_kernel(const bf16_t* __restrict__ src, int lds_, bf16_t* 
     }
 }
 
+// conv_in (8 -> 320 channels, 3x3): as an implicit GEMM its K = 9 taps x a 64-channel slice of which 8 channels are real - eight
+// times the MFMAs of the work. Gathered once into rows of 9 x 8 = 72 real K elements (+ 56 zeros: two K tiles of 64) it is a plain
+// [M x 128] x [128 x 320] GEMM: 241 -> ~55 us at level 0 of the 1024 config. out[row][16 t .. 16 t + 15] (bytes) = the 8 channels
+// of tap t = kh * 3 + kw of the row's pixel (zeros outside the image), t = 9 .. 15 zero. One 16-byte piece per thread.
+__global__ void im2col3x3_c8_kernel(const bf16_t* __restrict__ x, int ldx, bf16_t* __restrict__ out, int ldo, int n_img, int H,
+                                    int W) {
+    const int64_t total = (int64_t)n_img * H * W * 16;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int t = (int)(idx & 15);
+        const int64_t row = idx >> 4;
+        uint4 v = make_uint4(0u, 0u, 0u, 0u);
+        if (t < 9) {
+            const int px = (int)(row % W);
+            const int64_t r1 = row / W;
+            const int py = (int)(r1 % H);
+            const int iy = py + t / 3 - 1, ix = px + t % 3 - 1;
+            if (iy >= 0 && iy < H && ix >= 0 && ix < W)
+                v = *reinterpret_cast<const uint4*>(x + (size_t)(row + (int64_t)(t / 3 - 1) * W + (t % 3 - 1)) * ldx);
+        }
+        *reinterpret_cast<uint4*>(out + (size_t)row * ldo + t * 8) = v;
+    }
+}
+
 __global__ void add_rows_kernel(const bf16_t* __restrict__ a, int lda, const bf16_t* __restrict__ b, int ldb,
                                 bf16_t* __restrict__ y, int ldy, int rows, int vecs) {
     const int64_t total = (int64_t)rows * vecs;
@@ -460,6 +483,16 @@ extern "C" int dc_copy2d(const uint16_t* src, int lds_, uint16_t* dst, int ldd, 
     const int64_t total = (int64_t)rows * (cols / 8);
     hipLaunchKernelGGL(copy2d_kernel, dim3(grid_for(total, 256, 8192)), dim3(256), 0, (hipStream_t)stream_, src, lds_, dst,
                        ldd, rows, cols / 8);
+    DC_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int dc_im2col3x3_c8(const uint16_t* x, int ldx, uint16_t* out, int ldo, int n_img, int H, int W, void* stream_) {
+    if (!x || !out) return DC_ERR_ARG;
+    if (ldx % 8 || ldo % 8 || ldo < 128 || n_img < 1 || H < 1 || W < 1 || ((uintptr_t)x & 15) || ((uintptr_t)out & 15)) return DC_ERR_SHAPE;
+    const int64_t total = (int64_t)n_img * H * W * 16;
+    hipLaunchKernelGGL(im2col3x3_c8_kernel, dim3(grid_for(total, 256, 16384)), dim3(256), 0, (hipStream_t)stream_, x, ldx, out, ldo,
+                       n_img, H, W);
     DC_CHECK_LAUNCH();
     return 0;
 }

@@ -328,7 +328,12 @@ class UNetModel(nn.Module):
             for j, (kind, a) in enumerate(blk):
                 p = f"{prefix}.{j}"
                 if kind == "conv_in":
-                    out.append({"conv": PackedWeight.conv3x3(self._p(p + ".weight"), self._p(p + ".bias"), device)})
+                    d = {"conv": PackedWeight.conv3x3(self._p(p + ".weight"), self._p(p + ".bias"), device)}
+                    if a["cin"] <= 8 and os.environ.get("DC_CONVIN_IM2COL", "1") != "0":
+                        # 8 input channels: gather the 9 taps into ONE 128-wide K (72 real) and run a plain GEMM - the implicit
+                        # conv spends nine K tiles of 64 on them (ops.im2col3x3_c8)
+                        d["lin8"] = PackedWeight.conv3x3_c8_as_linear(self._p(p + ".weight"), self._p(p + ".bias"), device)
+                    out.append(d)
                 elif kind == "res":
                     d = {"gn1": (f32(p + ".in_layers.0.weight"), f32(p + ".in_layers.0.bias")),
                          "conv1": PackedWeight.conv3x3(self._p(p + ".in_layers.2.weight"), self._p(p + ".in_layers.2.bias"), device),
@@ -556,7 +561,12 @@ class UNetModel(nn.Module):
             if kind == "conv_in":
                 conv = dict(IH=g["H"], IW=g["W"], OH=g["H"], OW=g["W"], stride=1, pad=1, ups=0)
                 dst = final(h.shape[0], a["cout"]) if last else A.get(out_tag, h.shape[0], a["cout"], device=dev)
-                h = ops.gemm(h, W["conv"], dst, conv=conv)
+                if "lin8" in W:
+                    cols = ops.im2col3x3_c8(h, A.get(out_tag + ".im2col", h.shape[0], 128, device=dev), n_img=h.shape[0] // (g["H"] * g["W"]),
+                                            H=g["H"], W=g["W"])
+                    h = ops.gemm(cols, W["lin8"], dst)
+                else:
+                    h = ops.gemm(h, W["conv"], dst, conv=conv)
             elif kind == "res":
                 h = self._res(W, h, g, out_tag, out=final(h.shape[0], a["cout"]) if last else None)
             elif kind == "spatial":

@@ -147,6 +147,18 @@ class PackedWeight:
         return pw
 
     @staticmethod
+    def conv3x3_c8_as_linear(weight, bias, device):
+        """nn.Conv2d 3x3 weight [Cout, Cin <= 8, 3, 3] -> the Linear weight [Cout][128] that goes with ops.im2col3x3_c8:
+        k = 8 (kh*3 + kw) + c, zeros elsewhere."""
+        co, ci = weight.shape[0], weight.shape[1]
+        assert ci <= 8
+        w = torch.zeros(co, 16, 8, dtype=weight.dtype)
+        w[:, :9, :ci] = weight.detach().permute(0, 2, 3, 1).reshape(co, 9, ci)
+        pw = PackedWeight._finish(w.reshape(co, 128), bias, device, 128, 1)
+        pw.k_real = 9 * ci
+        return pw
+
+    @staticmethod
     def tconv3(weight, bias, device):
         """nn.Conv3d (3,1,1) weight [Cout, Cin, 3, 1, 1] -> [Cout][kt][Cin]."""
         co, ci = weight.shape[0], weight.shape[1]
@@ -620,6 +632,16 @@ def rows_to_nchw(rows, y, *, N, Cc, HW, scale=1.0):
     check(_hip.lib().dc_rows_to_nchw(_ptr(rows), rows.stride(0), 1 if rows.dtype == torch.float32 else 0, _ptr(y),
                                      N, Cc, HW, scale, stream_ptr()), "dc_rows_to_nchw")
     return y
+
+
+def im2col3x3_c8(x, out, *, n_img, H, W):
+    """rows [n_img*H*W, >= 8] (first 8 channels) -> rows [n_img*H*W, 128]: 9 taps x 8 channels + zeros (dc_im2col3x3_c8)."""
+    _rows(x, "x"); _rows(out, "out")
+    M = n_img * H * W
+    _need_rows(x, M, 8, "x"); _need_rows(out, M, 128, "out")
+    _launch("im2col3x3_c8", 0.0, 2.0 * M * (16 + 256), _hip.lib().dc_im2col3x3_c8, _ptr(x), x.stride(0), _ptr(out), out.stride(0),
+            n_img, H, W, stream_ptr())
+    return out
 
 
 def copy2d(src, dst, cols=None):

@@ -145,6 +145,13 @@ int dc_pack_latent(const float* x, const float* cc, uint16_t* out, int B, int Cx
 int dc_nchw_to_rows(const float* x, uint16_t* out, int N, int C, int HW, int c_pad, float scale, void* stream);
 int dc_rows_to_nchw(const void* rows, int ld, int rows_f32, float* y, int N, int C, int HW, float scale, void* stream);
 
+/* im2col for a 3x3 / stride 1 / pad 1 conv with <= 8 input channels (the UNet's conv_in: 4 latent + 4 concat channels,
+ * openaimodel3d.py:379-381 `conv_nd(dims, in_channels, model_channels, 3, padding=1)`): x rows [n_img*H*W][ldx] bf16 whose first
+ * 8 channels are read -> out rows [n_img*H*W][ldo >= 128]: elements 8 t .. 8 t + 7 = the 8 channels of tap t = kh*3 + kw (zeros
+ * outside the image), elements 72 .. 127 zero. The conv is then dc_gemm_conv (mode 0) on these rows with the weight reordered to
+ * [Cout][128] (k = 8 (kh*3 + kw) + c): two K tiles instead of nine, each eight times denser. */
+int dc_im2col3x3_c8(const uint16_t* x, int ldx, uint16_t* out, int ldo, int n_img, int H, int W, void* stream);
+
 /* 2-D strided copy of bf16 rows (skip-connection concat: torch.cat openaimodel3d.py:596). cols % 8 == 0. */
 int dc_copy2d(const uint16_t* src, int lds, uint16_t* dst, int ldd, int rows, int cols, void* stream);
 

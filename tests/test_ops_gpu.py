@@ -728,6 +728,30 @@ def test_gemm_and_tconv_pipe_plan(ops, gemm_plan):
     test_tconv3_ragged_wide(ops)
 
 
+# ---- conv_in as im2col (9 taps x 8 channels -> one 128-wide K) + plain GEMM, against torch and against the implicit-GEMM conv
+@pytest.mark.parametrize("n,ci,H,W", [(3, 8, 17, 23), (32, 8, 32, 32), (2, 5, 9, 40)])
+def test_conv_in_im2col_c8(ops, n, ci, H, W):
+    g = torch.Generator().manual_seed(23)
+    Co = 320
+    x = torch.randn(n, ci, H, W, generator=g).to(torch.bfloat16)
+    w = torch.randn(Co, ci, 3, 3, generator=g) * (9 * ci) ** -0.5
+    b = torch.randn(Co, generator=g)
+    ref = F.conv2d(x.float(), bf(w).float(), b, padding=1).permute(0, 2, 3, 1).reshape(-1, Co)
+    rows = torch.zeros(n * H * W, 64, dtype=torch.bfloat16)                    # the x_rows layout: 8 channels in a 64-wide row
+    rows[:, :ci] = x.permute(0, 2, 3, 1).reshape(-1, ci)
+    rows = rows.to(DEV)
+    cols = torch.full((n * H * W, 128), 7.0, dtype=torch.bfloat16, device=DEV)  # every element must be overwritten
+    ops.im2col3x3_c8(rows, cols, n_img=n, H=H, W=W)
+    assert cols[:, 72:].abs().max().item() == 0
+    pw = ops.PackedWeight.conv3x3_c8_as_linear(w, b, DEV)
+    out = torch.empty(n * H * W, Co, dtype=torch.bfloat16, device=DEV)
+    ops.gemm(cols, pw, out)
+    assert rel_l2(out, ref) < 4e-3
+    out2 = torch.empty_like(out)
+    ops.gemm(rows, ops.PackedWeight.conv3x3(w, b, DEV), out2, conv=dict(IH=H, IW=W, OH=H, OW=W, stride=1, pad=1, ups=0))
+    assert rel_l2(out, out2) < 3e-3                                            # same products, another summation order
+
+
 # ---- the ping-pong kernel (gemm_pp.h: 4-wave workgroups, two per CU, GEGLU formed in registers) behind plan bit 4 (16: default,
 # K <= 640) and bit 5 (32: any K)
 @pytest.mark.parametrize("gemm_plan", [51, 19, 3], indirect=True)
