@@ -68,9 +68,10 @@ def _threads():
     return max(1, min(n, 16))
 
 
-def _build(cname):
+def _build(cname, sd=None):
     """This package's LatentVisualDiffusion from the released YAML (Identity conditioners, as bench.py) with the
-    per-name seeded recipe weights in the UNet; returns (model on the GPU, oracle cfg, oracle state dict)."""
+    per-name seeded recipe weights in the UNet; returns (model on the GPU, oracle cfg, oracle state dict). `sd`: a recipe
+    state dict already drawn for the same architecture (the 512 / 1024 YAMLs share one; drawing 1.44 B normals takes ~20 s)."""
     from dynamicrafter_amd.utils.utils import instantiate_from_config
     from oracle import unet as ounet
     from oracle.weights import fill_state_dict
@@ -80,7 +81,8 @@ def _build(cname):
         p[k] = {"target": "torch.nn.Identity"}
     model = instantiate_from_config(cfg["model"])
     ocfg = ounet.UNetCfg.from_params(p["unet_config"]["params"])
-    sd = fill_state_dict(ounet.unet_param_shapes(ocfg), seed=12)
+    if sd is None:
+        sd = fill_state_dict(ounet.unet_param_shapes(ocfg), seed=12)
     model.model.diffusion_model.load_state_dict(sd, strict=True)
     return model.to(DEV).eval(), ocfg, sd
 
@@ -242,23 +244,28 @@ def test_unet_40x64_config2_and_5(model_v):
     assert out["guided"]["g"] < GUIDED_TOL and out["guided"]["x_prev"] < GUIDED_STEP_TOL
 
 
-def test_unet_32x32_config1():
+@pytest.fixture(scope="module")
+def model_eps():
+    """The inference_256 model (eps-parameterisation, learnable image-attention scale): shared by the two config-1 tests."""
+    m = _build("inference_256_v1.0.yaml")
+    yield m
+    del m
+    gc.collect()
+    torch.cuda.empty_cache()
+
+
+def test_unet_32x32_config1(model_eps):
     """BASELINE config 1: inference_256 (eps-parameterisation, learnable image-attention scale, fs 3) at 16x32x32,
     `uniform` spacing, eta = 0, no guidance rescale; cond branch also against the reference's own output."""
-    model, ocfg, sd = _build("inference_256_v1.0.yaml")
-    try:
-        g = np.load(os.path.join(G, "unet_fullsize_256_32x32.npz"))
-        x, cc, ctx = (torch.from_numpy(g[k]) for k in ("x", "c_concat", "context"))
-        uc_ctx = _rnd(*ctx.shape, seed=324)
-        fs = torch.from_numpy(g["fs"])
-        out = _run_case(model, ocfg, sd, x=x, cc=cc, ctx=ctx, uc_ctx=uc_ctx, fs=fs, disc="uniform", eta=0.0, gr=0.0,
-                        tag="256", golden_y=torch.from_numpy(g["y"])[0], golden_t=int(g["timesteps"][0]))
-        assert out["t_step"] == int(g["timesteps"][0])
-        assert out["guided"]["g"] < GUIDED_TOL and out["guided"]["x_prev"] < GUIDED_STEP_TOL
-    finally:
-        del model, sd
-        gc.collect()
-        torch.cuda.empty_cache()
+    model, ocfg, sd = model_eps
+    g = np.load(os.path.join(G, "unet_fullsize_256_32x32.npz"))
+    x, cc, ctx = (torch.from_numpy(g[k]) for k in ("x", "c_concat", "context"))
+    uc_ctx = _rnd(*ctx.shape, seed=324)
+    fs = torch.from_numpy(g["fs"])
+    out = _run_case(model, ocfg, sd, x=x, cc=cc, ctx=ctx, uc_ctx=uc_ctx, fs=fs, disc="uniform", eta=0.0, gr=0.0,
+                    tag="256", golden_y=torch.from_numpy(g["y"])[0], golden_t=int(g["timesteps"][0]))
+    assert out["t_step"] == int(g["timesteps"][0])
+    assert out["guided"]["g"] < GUIDED_TOL and out["guided"]["x_prev"] < GUIDED_STEP_TOL
 
 
 # ---- multi-step parity at full width (VERDICT r3 weak 1 / missing 3): the drift of the bf16 residual stream over steps is a
@@ -272,11 +279,12 @@ TRAJ256_TOL = {"eta0": (2.6e-2, 2.9e-2, 2.9e-2), "eta1": (3.5e-2, 3.6e-2, 3.6e-2
 TRAJ512_TOL = 4.4e-2
 
 
-def test_trajectory_fullwidth_10_steps_vs_reference():
+def test_trajectory_fullwidth_10_steps_vs_reference(model_eps):
     """BASELINE config 1 as the REFERENCE ran it (tests/golden/trajectory_fullwidth_256.npz: inference_256, the 1.44 B-parameter
     UNet, latent 16x32x32, DDIM 10 `uniform`, CFG 7.5, eta = 0 and eta = 1 with injected noises): the HIP sampler - captured
-    step graph, batched cond + uncond - replays it, x and pred_x0 after steps 1 / 5 / 10 against the reference's; the oracle
-    replays the eta = 0 run over all ten steps against the same fixture (the CPU suite checks its first step only)."""
+    step graph, batched cond + uncond - replays it, x and pred_x0 after steps 1 / 5 / 10 against the reference's. With
+    DC_TEST_LONG=1 the oracle also replays the eta = 0 run over all ten steps against the same fixture (75 - 100 s of host time;
+    measured max-rel 3.8e-6, profiles/r04_gpu_pytest.log - the CPU suite checks its first step on every run)."""
     from dynamicrafter_amd.lvdm.models.samplers.ddim import DDIMSampler
     from oracle import ddim as oddim
     from oracle import unet as ounet
@@ -284,43 +292,40 @@ def test_trajectory_fullwidth_10_steps_vs_reference():
     torch.set_num_threads(_threads())
     g = np.load(os.path.join(G, "trajectory_fullwidth_256.npz"))
     x_T, cc, ctx, uctx, fs, noises = fullwidth_trajectory_inputs(g)
-    model, ocfg, sd = _build("inference_256_v1.0.yaml")
-    try:
-        cond = {"c_crossattn": [ctx.to(DEV)], "c_concat": [cc.to(DEV)]}
-        uc = {"c_crossattn": [uctx.to(DEV)], "c_concat": [cc.to(DEV)]}
-        keep = [int(k) for k in g["keep"]]
-        for tag, eta in (("eta0", 0.0), ("eta1", 1.0)):
-            out, inter = DDIMSampler(model).sample(
-                S=10, batch_size=1, shape=tuple(x_T.shape[1:]), conditioning=cond, verbose=False,
-                unconditional_guidance_scale=7.5, unconditional_conditioning=uc, eta=eta, x_T=x_T.to(DEV), fs=fs.to(DEV),
-                timestep_spacing="uniform", guidance_rescale=0.0, log_every_t=1, use_graph=True,
-                noises=torch.stack(noises).to(DEV) if eta > 0 else None)
-            assert len(inter["x_inter"]) == 11 and torch.equal(inter["x_inter"][10], out)
-            rx = [rel_l2(inter["x_inter"][k], g[f"{tag}/x_{k}"]) for k in keep]
-            rp = [rel_l2(inter["pred_x0"][k], g[f"{tag}/pred_x0_{k}"]) for k in keep]
-            print(f"\n[trajectory 256 full width, {tag}] HIP vs REFERENCE rel-L2 after steps {keep}: x "
-                  + " / ".join(f"{v:.3e}" for v in rx) + "; pred_x0 " + " / ".join(f"{v:.3e}" for v in rp))
-            assert torch.isfinite(out).all()
-            for v, tol in zip(rx, TRAJ256_TOL[tag]):
-                assert v < tol, (tag, rx)
-        # the oracle over all ten steps of the eta = 0 run (pins the checker at full width over the whole trajectory)
-        ms = oddim.ModelSchedule(parameterization="eps")
-        sc = oddim.DDIMSchedule(ms, 10, "uniform", 0.0)
-        tr = []
-        t0 = time.perf_counter()
-        oddim.ddim_sample(lambda x, t, c, fs=None: ounet.unet_forward(sd, ocfg, torch.cat([x, cc], 1), t, c, fs), sc, x_T, ctx, uctx,
-                          cfg_scale=7.5, guidance_rescale=0.0, fs=fs, trace=tr)
-        mo = [maxrel(tr[k - 1][0], g[f"eta0/x_{k}"]) for k in keep] + [maxrel(tr[k - 1][1], g[f"eta0/pred_x0_{k}"]) for k in keep]
-        print(f"[trajectory 256 full width] oracle vs REFERENCE max-rel (x_1, x_5, x_10, pred_x0_1, _5, _10): "
-              + " ".join(f"{v:.1e}" for v in mo) + f"; oracle 10 steps {time.perf_counter() - t0:.0f} s")
-        assert max(mo) < 1e-3
-    finally:
-        del model, sd
-        gc.collect()
-        torch.cuda.empty_cache()
+    model, ocfg, sd = model_eps
+    cond = {"c_crossattn": [ctx.to(DEV)], "c_concat": [cc.to(DEV)]}
+    uc = {"c_crossattn": [uctx.to(DEV)], "c_concat": [cc.to(DEV)]}
+    keep = [int(k) for k in g["keep"]]
+    for tag, eta in (("eta0", 0.0), ("eta1", 1.0)):
+        out, inter = DDIMSampler(model).sample(
+            S=10, batch_size=1, shape=tuple(x_T.shape[1:]), conditioning=cond, verbose=False,
+            unconditional_guidance_scale=7.5, unconditional_conditioning=uc, eta=eta, x_T=x_T.to(DEV), fs=fs.to(DEV),
+            timestep_spacing="uniform", guidance_rescale=0.0, log_every_t=1, use_graph=True,
+            noises=torch.stack(noises).to(DEV) if eta > 0 else None)
+        assert len(inter["x_inter"]) == 11 and torch.equal(inter["x_inter"][10], out)
+        rx = [rel_l2(inter["x_inter"][k], g[f"{tag}/x_{k}"]) for k in keep]
+        rp = [rel_l2(inter["pred_x0"][k], g[f"{tag}/pred_x0_{k}"]) for k in keep]
+        print(f"\n[trajectory 256 full width, {tag}] HIP vs REFERENCE rel-L2 after steps {keep}: x "
+              + " / ".join(f"{v:.3e}" for v in rx) + "; pred_x0 " + " / ".join(f"{v:.3e}" for v in rp))
+        assert torch.isfinite(out).all()
+        for v, tol in zip(rx, TRAJ256_TOL[tag]):
+            assert v < tol, (tag, rx)
+    if os.environ.get("DC_TEST_LONG", "0") != "1":
+        return
+    # the oracle over all ten steps of the eta = 0 run (pins the checker at full width over the whole trajectory)
+    ms = oddim.ModelSchedule(parameterization="eps")
+    sc = oddim.DDIMSchedule(ms, 10, "uniform", 0.0)
+    tr = []
+    t0 = time.perf_counter()
+    oddim.ddim_sample(lambda x, t, c, fs=None: ounet.unet_forward(sd, ocfg, torch.cat([x, cc], 1), t, c, fs), sc, x_T, ctx, uctx,
+                      cfg_scale=7.5, guidance_rescale=0.0, fs=fs, trace=tr)
+    mo = [maxrel(tr[k - 1][0], g[f"eta0/x_{k}"]) for k in keep] + [maxrel(tr[k - 1][1], g[f"eta0/pred_x0_{k}"]) for k in keep]
+    print(f"[trajectory 256 full width] oracle vs REFERENCE max-rel (x_1, x_5, x_10, pred_x0_1, _5, _10): "
+          + " ".join(f"{v:.1e}" for v in mo) + f"; oracle 10 steps {time.perf_counter() - t0:.0f} s")
+    assert max(mo) < 1e-3
 
 
-def test_trajectory_5_guided_steps_40x64_vs_oracle():
+def test_trajectory_5_guided_steps_40x64_vs_oracle(model_v):
     """Five guided steps at the latent of BASELINE configs 2 / 5 (inference_512: v-parameterisation, zero terminal SNR, dynamic
     rescale 0.7, `uniform_trailing`, eta = 1, CFG 7.5, guidance rescale 0.7, interp concat pattern, fs 5) - HIP (captured graph)
     against the oracle run on the box's host cores over the same five steps; rel-L2 after every step is printed."""
@@ -328,7 +333,7 @@ def test_trajectory_5_guided_steps_40x64_vs_oracle():
     from oracle import ddim as oddim
     from oracle import unet as ounet
     torch.set_num_threads(_threads())
-    model, ocfg, sd = _build("inference_512_v1.0.yaml")
+    model, ocfg, sd = _build("inference_512_v1.0.yaml", sd=model_v[2])        # same architecture and recipe weights as the 1024 model
     try:
         g = np.load(os.path.join(G, "unet_fullsize_512_40x64_interp.npz"))
         x_T, cc, ctx = (torch.from_numpy(g[k]) for k in ("x", "c_concat", "context"))
@@ -356,7 +361,7 @@ def test_trajectory_5_guided_steps_40x64_vs_oracle():
         assert torch.isfinite(out).all()
         assert max(rx) < TRAJ512_TOL, rx
     finally:
-        del model, sd
+        del model
         gc.collect()
         torch.cuda.empty_cache()
 
