@@ -59,6 +59,7 @@ SIGNATURES = {
     "dc_ff_geglu_proj_fused320": (_I, [_P, _I, _P, _P, _F, _P, _P, _P, _P, _P, _P, _P, _I, _P, _I, _I, _P]),
     "dc_ln_linear": (_I, [_P, _I, _I, _P, _P, _F, _P, _P, _P, _I, _I, _I, _P]),
     "dc_ln_qkv_temporal_attn320": (_I, [_P, _I, _P, _P, _F, _P, _P, _I, _I, _I, _I, _F, _P]),
+    "dc_ln_qkv_temporal_attn640": (_I, [_P, _I, _P, _P, _F, _P, _P, _I, _I, _I, _I, _F, _P]),
     "dc_gn_silu_tconv3": (_I, [_P, _I, _I, _P, _P, _P, _I, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _P]),
     "dc_groupnorm_stats": (_I, [_P, _I, _I, _I, _I, _I, _F, _P, _P, _P]),
     "dc_gn_linear": (_I, [_P, _I, _I, _P, _P, _P, _I, _I, _P, _P, _P, _I, _I, _I, _P]),

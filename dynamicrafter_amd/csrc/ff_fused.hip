@@ -840,27 +840,37 @@ void norm_linear_kernel(const LlParams p) {
 // path has them (q, k, v, P), the softmax is fp32.
 constexpr int TA_VLD = 192;                    // bytes per v row in the patch (flash kernel's V_LD)
 constexpr int TA_PATCH = 32 * TA_VLD;          // 6 KB per wave: v [32 rows][64 d], then the output rows of the head
-constexpr int TA_LDS = 2 * LW_STAGE + 4 * TA_PATCH + 2 * FD * 4;
+constexpr int ta_ring(int kh) { return kh == 1 ? 2 : 4; }      // weight stages in LDS (dim 640 runs one workgroup per CU: nobody else
+                                                                // covers the L2 latency of a stage, so it is requested three stages ahead)
+constexpr int ta_lds(int kh) { return ta_ring(kh) * LW_STAGE + 4 * TA_PATCH + 2 * FD * kh * 4; }
 
 struct TaParams {
     const bf16_t* X; int ldx;
-    const bf16_t* W;             // [>= 960][320]: to_q, to_k, to_v rows
+    const bf16_t* W;             // [>= 3 C][C]: to_q, to_k, to_v rows (C = 320 KH)
     bf16_t* O; int ldo;
     const float* ln_g; const float* ln_b; float ln_eps;
     int HW;                      // positions per frame (% 8 == 0); T = 16
     float c;                     // scale * log2(e)
 };
 
-__global__ __launch_bounds__(256, 2)
-void ln_qkv_tattn320_kernel(const TaParams p) {
+// KH = 1: dim 320 (level 0), 5 heads, two workgroups per CU. KH = 2: dim 640 (level 1), 10 heads: the X fragments of a row take
+// 160 registers, a weight chunk (32 rows x 640 k) passes the ring as two stages (k halves, as norm_linear_kernel does), one
+// workgroup per CU.
+template <int KH>
+__global__ __launch_bounds__(256, KH == 1 ? 2 : 1)
+void ln_qkv_tattn_kernel(const TaParams p) {
+    constexpr int KD = FD * KH;
+    constexpr int NS = ta_ring(KH);                               // ring depth: a stage is requested NS - 1 stages ahead
+    constexpr int SPH = 6 * KH;                                   // stages per head (SPH % NS == 0: slots are compile-time)
+    static_assert(SPH % NS == 0, "ring phase");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int fr = lane & 31, fh = lane >> 5;
     const unsigned lds_base = (unsigned)(unsigned long)((lds_char_t*)smem);
-    char* const vpatch = smem + 2 * LW_STAGE + wave * TA_PATCH;
-    float* const lns = reinterpret_cast<float*>(smem + 2 * LW_STAGE + 4 * TA_PATCH);
+    char* const vpatch = smem + NS * LW_STAGE + wave * TA_PATCH;
+    float* const lns = reinterpret_cast<float*>(smem + NS * LW_STAGE + 4 * TA_PATCH);
     const int gpb = p.HW >> 3;                                    // 8-position groups per clip
     const int b = (int)blockIdx.x / gpb, p0 = ((int)blockIdx.x - b * gpb) * 8 + 2 * wave;
     auto grow = [&](int r) { return ((size_t)(b * 16 + (r & 15))) * p.HW + p0 + (r >> 4); };      // wave row r -> tensor row
@@ -870,7 +880,7 @@ void ln_qkv_tattn320_kernel(const TaParams p) {
     for (int i = 0; i < 5; ++i) {
         const int u = wave * 5 + i;
         const int t = u >> 2, g = u & 3;
-        vo[i] = (unsigned)((g * 8 + (lane >> 3)) * (FD * 2) + t * 128 + (((lane & 7) ^ ((g * 4 + (lane >> 4)) & 7)) << 4));
+        vo[i] = (unsigned)((g * 8 + (lane >> 3)) * (KD * 2) + t * 128 + (((lane & 7) ^ ((g * 4 + (lane >> 4)) & 7)) << 4));
         asm volatile("" : "+v"(vo[i]));
     }
     auto dma_piece = [&](unsigned lds_dst, unsigned voff, uint64_t sbase) __attribute__((always_inline)) {
@@ -885,64 +895,84 @@ void ln_qkv_tattn320_kernel(const TaParams p) {
             : "s"(lds_dst), "v"(voff), "s"(sbase)
             : "memory");
     };
-    // chunk (head h, part): part 0,1 = q halves, 2,3 = k halves, 4,5 = v halves -> weight rows (part/2) * 320 + 64 h + 32 (part&1)
-    auto w_base = [&](int h, int part) {
-        return (uint64_t)(uintptr_t)p.W + (uint64_t)((part >> 1) * FD + 64 * h + 32 * (part & 1)) * (FD * 2);
+    // chunk (head h, part): part 0,1 = q halves, 2,3 = k halves, 4,5 = v halves -> weight rows (part/2) * C + 64 h + 32 (part&1);
+    // stage (chunk, kh): the k half kh of those rows
+    auto w_base = [&](int h, int part, int kh) {
+        return (uint64_t)(uintptr_t)p.W + (uint64_t)((part >> 1) * KD + 64 * h + 32 * (part & 1)) * (KD * 2) + (uint64_t)kh * (FD * 2);
     };
     auto w_dst = [&](int slot, int i) { return lds_base + slot * LW_STAGE + (wave * 5 + i) * 1024; };
 
+    // gridDim.y workgroups share the heads of a row tile (DC_TA_HSPLIT=2 at dim 640: heads 0-4 / 5-9, x read twice - no faster)
+    const int hpw = 5 * KH / (int)gridDim.y;
+    const int h_begin = (int)blockIdx.y * hpw, h_end = h_begin + hpw;
+    // stage index inside a head: lin = part * KH + kh (compile-time in the unrolled loops below)
 #pragma unroll
-    for (int i = 0; i < 5; ++i) dma_piece(w_dst(0, i), vo[i], w_base(0, 0));
+    for (int d = 0; d < NS - 1; ++d)
+#pragma unroll
+        for (int i = 0; i < 5; ++i) dma_piece(w_dst(d, i), vo[i], w_base(h_begin + d / SPH, (d % SPH) / KH, d % KH));
 
-    bf16x8_t xf[FD / 16];
+    bf16x8_t xf[KD / 16];
     {
         const bf16_t* xr = p.X + grow(fr) * p.ldx + fh * 8;
 #pragma unroll
-        for (int kk = 0; kk < FD / 16; ++kk) xf[kk] = *reinterpret_cast<const bf16x8_t*>(xr + kk * 16);
-        for (int i = tid; i < FD; i += 256) { lns[i] = p.ln_g[i]; lns[FD + i] = p.ln_b[i]; }
+        for (int kk = 0; kk < KD / 16; ++kk) xf[kk] = *reinterpret_cast<const bf16x8_t*>(xr + kk * 16);
+        for (int i = tid; i < KD; i += 256) { lns[i] = p.ln_g[i]; lns[KD + i] = p.ln_b[i]; }
     }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    ln_rows_inplace<FD>(xf, lns, lns + FD, p.ln_eps, fh);
+    ln_rows_inplace<KD>(xf, lns, lns + KD, p.ln_eps, fh);
 
     constexpr int PD = 6;
-    int slot = 0;
     const int li = lane & 15;
     const int tr_off = (li >> 2) * TA_VLD + (((lane >> 4) & 1) * 16 + (li & 3) * 4) * 2;      // transposed v read (flash kernel)
     const int px = fr >> 4;                                       // which of the wave's two positions this lane's row is
-    for (int h = 0; h < 5; ++h) {
+    for (int h = h_begin; h < h_end; ++h) {
         bf16x8_t qf[4], kf[4];
 #pragma unroll
         for (int part = 0; part < 6; ++part) {
-            if (h > 0 || part > 0) {
-                // this chunk's weights were issued during the previous chunk, in front of the 4 output stores of a head
-                if (part == 0) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __builtin_amdgcn_s_barrier();
-                asm volatile("" ::: "memory");
-            }
-            const char* s1 = smem + slot * LW_STAGE;
             f32x16_t acc;
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-            bf16x8_t wr[PD];
-            auto rd = [&](int kk, int sl) __attribute__((always_inline)) {
-                wr[sl] = *(lds_vfrag_t*)((lds_char_t*)s1 + (kk >> 2) * 4096 + off128(fr, (kk & 3) * 2 + fh));
-            };
 #pragma unroll
-            for (int kk = 0; kk < PD; ++kk) rd(kk, kk);
-            const bool more = part < 5 || h < 4;
-            const uint64_t nb = part < 5 ? w_base(h, part + 1) : w_base(h + 1, 0);
+            for (int kh = 0; kh < KH; ++kh) {
+                const int lin = part * KH + kh;                   // (compile-time after unrolling)
+                const int slot = lin % NS;
+                if (h > h_begin || lin > 0) {
+                    // this stage's 5 pieces were issued NS - 1 stages ago; younger than them are the pieces of the stages between
+                    // (5 each - fewer at the very end) and, on the first stage of a head, the previous head's 4 output stores
+                    const int rem = (h + 1 == h_end) ? SPH - 1 - lin : NS;         // stages behind this one (>= NS - 2 is all that matters)
+                    const int younger = rem < NS - 2 ? rem : NS - 2;
+                    const int n = 5 * younger + ((lin == 0) ? 4 : 0);
+                    if (n >= 14) asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
+                    else if (n >= 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+                    else if (n >= 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+                    else if (n >= 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();
+                    asm volatile("" ::: "memory");
+                }
+                const char* s1 = smem + slot * LW_STAGE;
+                bf16x8_t wr[PD];
+                auto rd = [&](int kk, int sl) __attribute__((always_inline)) {
+                    wr[sl] = *(lds_vfrag_t*)((lds_char_t*)s1 + (kk >> 2) * 4096 + off128(fr, (kk & 3) * 2 + fh));
+                };
 #pragma unroll
-            for (int kk = 0; kk < FD / 16; ++kk) {
-                bf16x8_t f = wr[kk % PD];
-                if (kk + PD < FD / 16) rd(kk + PD, kk % PD);
-                asm volatile("" : "+v"(f));
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f, xf[kk], acc, 0, 0, 0);
-                if (kk < 5 && more) dma_piece(w_dst(slot ^ 1, kk), vo[kk], nb);
+                for (int kk = 0; kk < PD; ++kk) rd(kk, kk);
+                // the stage NS - 1 ahead goes into the slot that stage lin - 1 has just left (every wave is past this stage's barrier)
+                const int nl = lin + NS - 1;
+                const int nh = h + nl / SPH;
+                const bool more = nh < h_end;
+                const uint64_t nb = w_base(nh, (nl % SPH) / KH, nl % KH);
+#pragma unroll
+                for (int kk = 0; kk < FD / 16; ++kk) {
+                    bf16x8_t f = wr[kk % PD];
+                    if (kk + PD < FD / 16) rd(kk + PD, kk % PD);
+                    asm volatile("" : "+v"(f));
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f, xf[kh * (FD / 16) + kk], acc, 0, 0, 0);
+                    if (kk < 5 && more) dma_piece(w_dst(nl % NS, kk), vo[kk], nb);
+                }
             }
-            slot ^= 1;
             if (part < 4) {
                 // q / k block of this row: the two operand fragments of k steps 2 (part & 1), + 1
 #pragma unroll
@@ -1362,20 +1392,34 @@ extern "C" int dc_gn_linear(const uint16_t* x, int ldx, int K, const float* gamm
     return launch_norm_linear(2, K, p, (hipStream_t)stream_);
 }
 
-extern "C" int dc_ln_qkv_temporal_attn320(const uint16_t* x, int ldx, const float* ln_gamma, const float* ln_beta, float ln_eps,
-                                          const uint16_t* wqkv, uint16_t* out, int ldo, int B, int T, int HW, float scale,
-                                          void* stream_) {
+template <int KH>
+static int launch_ln_qkv_tattn(const uint16_t* x, int ldx, const float* ln_gamma, const float* ln_beta, float ln_eps,
+                               const uint16_t* wqkv, uint16_t* out, int ldo, int B, int T, int HW, float scale, void* stream_) {
     if (!x || !ln_gamma || !ln_beta || !wqkv || !out) return DC_ERR_ARG;
     if (B < 1 || T != 16 || HW < 8 || HW % 8 || ldx % 8 || ldo % 8) return DC_ERR_SHAPE;
     if (((uintptr_t)x | (uintptr_t)out | (uintptr_t)wqkv) % 16) return DC_ERR_SHAPE;
     static DcLdsOnce lds_once;
-    if (const int e = lds_once.ensure(reinterpret_cast<const void*>(&ln_qkv_tattn320_kernel), TA_LDS)) return e;
+    if (const int e = lds_once.ensure(reinterpret_cast<const void*>(&ln_qkv_tattn_kernel<KH>), ta_lds(KH))) return e;
     TaParams p;
     p.X = x; p.ldx = ldx; p.W = wqkv; p.O = out; p.ldo = ldo; p.ln_g = ln_gamma; p.ln_b = ln_beta; p.ln_eps = ln_eps;
     p.HW = HW; p.c = scale * 1.4426950408889634f;
-    hipLaunchKernelGGL(ln_qkv_tattn320_kernel, dim3((unsigned)(B * (HW / 8))), dim3(256), TA_LDS, (hipStream_t)stream_, p);
+    static const int hsplit_env = [] { const char* e = getenv("DC_TA_HSPLIT"); return e ? atoi(e) : 0; }();
+    const int hsplit = (KH == 2 && hsplit_env == 2) ? 2 : 1;      // heads of a row tile over 1 or 2 workgroups (measured: 256-261 vs 266-285 us)
+    hipLaunchKernelGGL(ln_qkv_tattn_kernel<KH>, dim3((unsigned)(B * (HW / 8)), hsplit), dim3(256), ta_lds(KH), (hipStream_t)stream_, p);
     DC_CHECK_LAUNCH();
     return 0;
+}
+
+extern "C" int dc_ln_qkv_temporal_attn320(const uint16_t* x, int ldx, const float* ln_gamma, const float* ln_beta, float ln_eps,
+                                          const uint16_t* wqkv, uint16_t* out, int ldo, int B, int T, int HW, float scale,
+                                          void* stream_) {
+    return launch_ln_qkv_tattn<1>(x, ldx, ln_gamma, ln_beta, ln_eps, wqkv, out, ldo, B, T, HW, scale, stream_);
+}
+
+extern "C" int dc_ln_qkv_temporal_attn640(const uint16_t* x, int ldx, const float* ln_gamma, const float* ln_beta, float ln_eps,
+                                          const uint16_t* wqkv, uint16_t* out, int ldo, int B, int T, int HW, float scale,
+                                          void* stream_) {
+    return launch_ln_qkv_tattn<2>(x, ldx, ln_gamma, ln_beta, ln_eps, wqkv, out, ldo, B, T, HW, scale, stream_);
 }
 
 template <int KH, bool RES>

@@ -29,6 +29,7 @@ _FF_FUSED = os.environ.get("DC_FF_FUSED", "1") != "0"
 _LN_FUSED = os.environ.get("DC_LN_FUSED", "1") != "0"      # A/B switches of the fused kernels in ff_fused.hip
 _LR_FUSED = os.environ.get("DC_LR_FUSED", "1") != "0"      # Linear + residual at K <= 640 in the X-stationary kernel
 _TA_FUSED = os.environ.get("DC_TA_FUSED", "1") != "0"
+_TA_FUSED_C = tuple(int(k) for k in os.environ.get("DC_TA_FUSED_C", "320,640").split(","))      # widths of the fused temporal attention
 _FFP_FUSED = os.environ.get("DC_FFP_FUSED", "1") != "0"
 _TC_FUSED = os.environ.get("DC_TC_FUSED", "1") != "0"
 # below this row count the tile GEMMs + norm kernels are used (the 1024 config's level-0/1 tensors have >= 73728 rows; at the
@@ -459,9 +460,9 @@ class UNetModel(nn.Module):
         A = self._arena
         M, dev, Cc = h.shape[0], h.device, heads * 64
         att = A.get("att", M, Cc, device=dev)
-        if _TA_FUSED and Cc == 320 and g["T"] == 16 and g["HW"] % 8 == 0 and M >= _FUSED_MIN_ROWS:
-            # level 0: LayerNorm, q/k/v and the attention over the 16 frames in one kernel - no [M, 960] qkv tensor
-            ops.ln_qkv_temporal_attn320(h, ln, Wa["qkv"], att, B=g["B"], T=16, HW=g["HW"], scale=0.125)
+        if _TA_FUSED and Cc in _TA_FUSED_C and g["T"] == 16 and g["HW"] % 8 == 0 and M >= _FUSED_MIN_ROWS:
+            # levels 0 / 1: LayerNorm, q/k/v and the attention over the 16 frames in one kernel - no [M, 3 C] qkv tensor
+            ops.ln_qkv_temporal_attn(h, ln, Wa["qkv"], att, B=g["B"], T=16, HW=g["HW"], scale=0.125)
             return self._lin_res(att, Wa["out"], h, h)
         qkv = self._ln_linear(h, ln, Wa["qkv"], A.get("qkv", M, 3 * Cc, device=dev))
         ops.temporal_attn(qkv, att, B=g["B"], T=g["T"], HW=g["HW"], heads=heads, scale=0.125)

@@ -486,20 +486,28 @@ def linear_residual(x, pw, residual, out):
     return out
 
 
-def ln_qkv_temporal_attn320(x, ln, pw_qkv, out, *, B, T, HW, scale, ln_eps=1e-5):
+def ln_qkv_temporal_attn(x, ln, pw_qkv, out, *, B, T, HW, scale, ln_eps=1e-5):
     """out = temporal self-attention (over the T = 16 frames of a position) of LayerNorm(x), q/k/v projected in the same
-    launch; dim 320 = 5 heads x 64; rows ordered (clip, frame, position)."""
+    launch; dim 320 = 5 heads x 64 or 640 = 10 heads x 64; rows ordered (clip, frame, position)."""
     _rows(x, "x"); _rows(out, "out")
     M = B * T * HW
-    if pw_qkv.K != 320 or pw_qkv.N != 960 or pw_qkv.bias is not None or T != 16 or HW % 8:
-        raise ValueError("ln_qkv_temporal_attn320: dim 320 (qkv weight [960, 320], no bias), T = 16, HW % 8 == 0")
+    Cc = pw_qkv.K
+    if Cc not in (320, 640) or pw_qkv.N != 3 * Cc or pw_qkv.bias is not None or T != 16 or HW % 8:
+        raise ValueError("ln_qkv_temporal_attn: dim 320 / 640 (qkv weight [3 C, C], no bias), T = 16, HW % 8 == 0")
     if x.data_ptr() == out.data_ptr():
-        raise ValueError("ln_qkv_temporal_attn320: out must not alias x")
-    _need_rows(x, M, 320, "x"); _need_rows(out, M, 320, "out"); _need(ln[0], 320, "ln gamma"); _need(ln[1], 320, "ln beta")
-    _launch("ln_qkv_temporal_attn320", 2.0 * M * 960 * 320 + 4.0 * M * T * 320, 4.0 * M * 320 + 2.0 * 960 * 320,
-            _hip.lib().dc_ln_qkv_temporal_attn320, _ptr(x), x.stride(0), _ptr(ln[0]), _ptr(ln[1]), ln_eps, _ptr(pw_qkv.w),
+        raise ValueError("ln_qkv_temporal_attn: out must not alias x")
+    _need_rows(x, M, Cc, "x"); _need_rows(out, M, Cc, "out"); _need(ln[0], Cc, "ln gamma"); _need(ln[1], Cc, "ln beta")
+    fn = _hip.lib().dc_ln_qkv_temporal_attn320 if Cc == 320 else _hip.lib().dc_ln_qkv_temporal_attn640
+    _launch(f"ln_qkv_temporal_attn{Cc}", 2.0 * M * 3 * Cc * Cc + 4.0 * M * T * Cc, 4.0 * M * Cc + 2.0 * 3 * Cc * Cc,
+            fn, _ptr(x), x.stride(0), _ptr(ln[0]), _ptr(ln[1]), ln_eps, _ptr(pw_qkv.w),
             _ptr(out), out.stride(0), B, T, HW, scale, stream_ptr())
     return out
+
+
+def ln_qkv_temporal_attn320(x, ln, pw_qkv, out, *, B, T, HW, scale, ln_eps=1e-5):
+    if pw_qkv.K != 320:
+        raise ValueError("ln_qkv_temporal_attn320: dim 320 (qkv weight [960, 320], no bias), T = 16, HW % 8 == 0")
+    return ln_qkv_temporal_attn(x, ln, pw_qkv, out, B=B, T=T, HW=HW, scale=scale, ln_eps=ln_eps)
 
 
 def gn_silu_tconv3(x, gamma, beta, stats, pw, out, *, B, T, HW, groups=32, residual=None):

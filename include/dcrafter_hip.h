@@ -267,6 +267,9 @@ int dc_linear_residual(const uint16_t* x, int ldx, int K, const uint16_t* w, con
  * (BasicTransformerBlock._forward) with CrossAttention.forward :101-125, at the UNet's level 0 */
 int dc_ln_qkv_temporal_attn320(const uint16_t* x, int ldx, const float* ln_gamma, const float* ln_beta, float ln_eps,
                                const uint16_t* wqkv, uint16_t* out, int ldo, int B, int T, int HW, float scale, void* stream);
+/* The same for dim 640 (10 heads x 64: level 1): wqkv bf16 [>= 1920][640]; out[M, 640]. */
+int dc_ln_qkv_temporal_attn640(const uint16_t* x, int ldx, const float* ln_gamma, const float* ln_beta, float ln_eps,
+                               const uint16_t* wqkv, uint16_t* out, int ldo, int B, int T, int HW, float scale, void* stream);
 
 /* GroupNorm (statistics from dc_groupnorm_stats, instances = clips) + SiLU + temporal convolution (3,1,1), zero padding in
  * time, (+ residual) for C = 320 or 640 input channels in one launch; rows ordered (clip, frame, position), T = 16,

@@ -1024,11 +1024,11 @@ def test_gn_linear_vs_groupnorm_plus_gemm(ops, n_inst, rpi, N, K):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("B,HW", [(1, 8), (2, 72), (2, 2304)])
-def test_ln_qkv_temporal_attn320_vs_three_kernels(ops, B, HW):
-    """dc_ln_qkv_temporal_attn320 = dc_layernorm -> dc_gemm_conv (qkv) -> dc_temporal_attn_d64, and = torch fp32"""
-    g = torch.Generator().manual_seed(B * HW)
-    T, C = 16, 320
+@pytest.mark.parametrize("B,HW,C", [(1, 8, 320), (2, 72, 320), (2, 2304, 320), (1, 8, 640), (2, 72, 640), (2, 2304, 640)])
+def test_ln_qkv_temporal_attn320_vs_three_kernels(ops, B, HW, C):
+    """dc_ln_qkv_temporal_attn320 / 640 = dc_layernorm -> dc_gemm_conv (qkv) -> dc_temporal_attn_d64, and = torch fp32"""
+    g = torch.Generator().manual_seed(B * HW + C)
+    T, heads = 16, C // 64
     M = B * T * HW
     x = (torch.randn(M, C, generator=g) * 1.2 + 0.3).to(torch.bfloat16)
     w = torch.randn(3 * C, C, generator=g) * C ** -0.5 * 1.5
@@ -1036,22 +1036,22 @@ def test_ln_qkv_temporal_attn320_vs_three_kernels(ops, B, HW):
     pw = ops.PackedWeight.linear(w, None, DEV)
     xd, gd, bd = x.to(DEV), gam.to(DEV), bet.to(DEV)
     out = torch.empty(M, C, dtype=torch.bfloat16, device=DEV)
-    ops.ln_qkv_temporal_attn320(xd, (gd, bd), pw, out, B=B, T=T, HW=HW, scale=0.125)
+    ops.ln_qkv_temporal_attn(xd, (gd, bd), pw, out, B=B, T=T, HW=HW, scale=0.125)
     n = torch.empty_like(xd)
     ops.layernorm(xd, n, gd, bd, 1e-5)
     qkv = torch.empty(M, 3 * C, dtype=torch.bfloat16, device=DEV)
     ops.gemm(n, pw, qkv)
     want = torch.empty_like(out)
-    ops.temporal_attn(qkv, want, B=B, T=T, HW=HW, heads=5, scale=0.125)
+    ops.temporal_attn(qkv, want, B=B, T=T, HW=HW, heads=heads, scale=0.125)
     assert rel_l2(out, want) < 4e-3
     # torch fp32: rows (b, t, p) -> per (b, p, head) attention over t
     nf = torch.nn.functional.layer_norm(x.float(), (C,), gam, bet, 1e-5)
-    q, k, v = (nf @ w.t()).reshape(B, T, HW, 3, 5, 64).permute(3, 0, 2, 4, 1, 5)      # [3][B, HW, heads, T, 64]
+    q, k, v = (nf @ w.t()).reshape(B, T, HW, 3, heads, 64).permute(3, 0, 2, 4, 1, 5)  # [3][B, HW, heads, T, 64]
     a = torch.softmax(q @ k.transpose(-1, -2) * 0.125, dim=-1) @ v                   # [B, HW, heads, T, 64]
     ref = a.permute(0, 3, 1, 2, 4).reshape(M, C)
     assert rel_l2(out.float().cpu(), ref) < 1e-2
     with pytest.raises(ValueError):
-        ops.ln_qkv_temporal_attn320(xd, (gd, bd), pw, xd, B=B, T=T, HW=HW, scale=0.125)
+        ops.ln_qkv_temporal_attn(xd, (gd, bd), pw, xd, B=B, T=T, HW=HW, scale=0.125)
 
 
 @pytest.mark.gpu
