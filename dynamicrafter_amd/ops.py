@@ -341,7 +341,7 @@ def groupnorm(x, y, gamma, beta, *, groups, n_inst, rows_per_inst, eps, silu):
     Cc = gamma.numel()
     l = _hip.lib()
     ws = _gn_workspace(x.device, int(l.dc_groupnorm_workspace_bytes(n_inst, groups, rows_per_inst)))
-    _launch("groupnorm(3 kernels)", 0.0, 6.0 * n_inst * rows_per_inst * Cc, l.dc_groupnorm, _ptr(x), x.stride(0), _ptr(y),
+    _launch("groupnorm(2-3 kernels)", 0.0, 6.0 * n_inst * rows_per_inst * Cc, l.dc_groupnorm, _ptr(x), x.stride(0), _ptr(y),
             y.stride(0), _ptr(gamma), _ptr(beta), Cc, groups, n_inst, rows_per_inst, eps, 1 if silu else 0, _ptr(ws),
             stream_ptr())
     return y
