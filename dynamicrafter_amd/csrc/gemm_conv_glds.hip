@@ -1081,7 +1081,7 @@ int dc_gemm_conv_glds_try(const DcGemmParams& p, hipStream_t stream) {
         // ping-pong kernel: measured ahead of the 8-wave kernel at K = 640 (547-560 vs 577-584 us on [73728 x 640 -> 2 x 2560]), level
         // with it at K = 1280, behind on the 18-row-panel level-3 launch (profiles/r04_pp_ab.txt): K <= 640 only
         // (plan bit 5 lifts the K limit: tests and same-box A/B)
-        if (geglu && (plan & 16) && ((plan & 32) || p.K <= 640) && pp_ok(p) && tiles_m * (n_out / 64) >= 1024) return launch_pp<true, 0>(p, stream);
+        if (geglu && (plan & 16) && ((plan & 32) || p.K <= 640) && pp_ok(p) && tiles_m * (n_out / 64) >= 1024) return launch_pp(p, stream);
         if (geglu) {
             // each workgroup re-streams its A panel once per N tile: the wider tile halves that traffic
             if (wide && n_out % 128 == 0 && tiles_m * (n_out / 128) >= 512) return launch_persist<256, true>(p, stream, 256);

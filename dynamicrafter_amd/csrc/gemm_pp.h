@@ -1,5 +1,5 @@
 // "Ping-pong" GEMM for the short-K launches whose epilogue is a large share of a tile: the GEGLU projections of levels 1-3
-// ([73728 x 640 -> 2 x 2560], [18432 x 1280 -> 2 x 5120], [4608 x 1280 -> 2 x 5120]) and the plain 128-wide linears of level 2
+// ([73728 x 640 -> 2 x 2560], [18432 x 1280 -> 2 x 5120], [4608 x 1280 -> 2 x 5120])
 // (included by gemm_conv_glds.hip inside its namespace, behind gemm_pipe.h / gemm_pipe16.h whose ring helpers it uses).
 //
 // Why another kernel. The persistent 8-wave kernel computes these at 0.27-0.35 of the matrix peak: PMC says MFMA busy 37-45 %,
@@ -52,19 +52,18 @@ __device__ __forceinline__ void pp_settle(gp_f32x4_t (&acc)[4][8]) {
     asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");
 }
 
-// GEGLU: out[M, N/2] = (x Wv^T + bv) * gelu(x Wg^T + bg), Wv = W rows [0, N/2), Wg = rows [N/2, N).   !GEGLU: out[M, N] = x W^T + b
-// (+ residual, EPI 1). Requirements (pp_ok): mode 0, K % 64 == 0, output columns % 64 == 0 (GEGLU) / % 128 == 0 (plain), 16-byte
+// out[M, N/2] = (x Wv^T + bv) * gelu(x Wg^T + bg), Wv = W rows [0, N/2), Wg = rows [N/2, N).
+// Requirements (pp_ok): DC_GEMM_GEGLU, mode 0, K % 32 == 0, output columns % 64 == 0, 16-byte
 // aligned rows, byte offsets below 2^31, no rowvec / alpha / fp32 output.
-template <bool GEGLU, int EPI>
 __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void gemm_pp_kernel(const DcGemmParams p, const GemmSplit sp, const int tile_group) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int BNOUT = GEGLU ? 64 : 128;
+    constexpr int BNOUT = 64;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lr = lane & 15, lq = lane >> 4;
 
-    const int n_out = GEGLU ? (p.N >> 1) : p.N;
+    const int n_out = p.N >> 1;
     const int tiles_n = n_out / BNOUT;
     const int tiles_m = (p.M + GBM - 1) / GBM;
     int tile_m, tile_n;
@@ -97,9 +96,7 @@ void gemm_pp_kernel(const DcGemmParams p, const GemmSplit sp, const int tile_gro
 #pragma unroll
     for (int j = 0; j < 2; ++j) {                           // weights: piece 2 wave + j = tile rows 16 (2 wave + j) .. + 15
         const int row = (2 * wave + j) * 16 + (lane >> 2);
-        int wrow;
-        if (GEGLU) wrow = row < 64 ? n0 + row : (p.N >> 1) + n0 + (row - 64);
-        else wrow = n0 + row;
+        int wrow = row < 64 ? n0 + row : (p.N >> 1) + n0 + (row - 64);
 #ifdef PP_DBG_ALIAS_W       // tool build: every workgroup reads weight tile 0
         wrow = row;
 #endif
@@ -253,96 +250,69 @@ void gemm_pp_kernel(const DcGemmParams p, const GemmSplit sp, const int tile_gro
     const int er = lane_e & 15, eq = lane_e >> 4;           // accumulator coordinates
     const int rrow = lane_e >> 3, rc = lane_e & 7;          // read-back coordinates: row of 8, 16-byte piece of the 128 bytes
     char* const cbase = reinterpret_cast<char*>(p.C);
-    const char* const rbase = reinterpret_cast<const char*>(p.residual);
-    constexpr int NPASS = GEGLU ? 1 : 2;                    // 64 output channels per pass
-    float4 bv[NPASS][4], bg[GEGLU ? 4 : 1];
+    float4 bv[4], bg[4];
 #pragma unroll
-    for (int ps = 0; ps < NPASS; ++ps)
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const int n = n0 + ps * 64 + c * 16 + 4 * eq;
-            bv[ps][c] = p.bias ? *reinterpret_cast<const float4*>(p.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
-            if constexpr (GEGLU) bg[c] = p.bias ? *reinterpret_cast<const float4*>(p.bias + (p.N >> 1) + n) : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
+    for (int c = 0; c < 4; ++c) {
+        const int n = n0 + c * 16 + 4 * eq;
+        bv[c] = p.bias ? *reinterpret_cast<const float4*>(p.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+        bg[c] = p.bias ? *reinterpret_cast<const float4*>(p.bias + (p.N >> 1) + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
 #pragma unroll
     for (int rb = 0; rb < 4; ++rb) {
+        unsigned co[2];
+        bool rok[2];
 #pragma unroll
-        for (int ps = 0; ps < NPASS; ++ps) {
-            u32x4_t rr[2];
-            unsigned co[2];
-            bool rok[2];
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                int mr = m0 + wave * 64 + rb * 16 + h * 8 + rrow;
-                rok[h] = mr < p.M;
-                if (!rok[h]) mr = p.M - 1;                  // clamped rows are loaded, never stored
-                co[h] = ((unsigned)mr * (unsigned)p.ldc + (unsigned)(n0 + ps * 64 + rc * 8)) * 2u;
-                if constexpr (EPI == 1)
-                    rr[h] = *reinterpret_cast<const u32x4_t*>(rbase + ((unsigned)mr * (unsigned)p.ldr + (unsigned)(n0 + ps * 64 + rc * 8)) * 2u);
-            }
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const int cb = GEGLU ? c : ps * 4 + c;
-                float4 v = make_float4(acc[rb][cb][0] + bv[ps][c].x, acc[rb][cb][1] + bv[ps][c].y, acc[rb][cb][2] + bv[ps][c].z,
-                                       acc[rb][cb][3] + bv[ps][c].w);
-                if constexpr (GEGLU) {
-                    v.x *= DC_GELU(acc[rb][c + 4][0] + bg[c].x); v.y *= DC_GELU(acc[rb][c + 4][1] + bg[c].y);
-                    v.z *= DC_GELU(acc[rb][c + 4][2] + bg[c].z); v.w *= DC_GELU(acc[rb][c + 4][3] + bg[c].w);
-                } else if (p.flags & DC_GEMM_GELU) {
-                    v.x = DC_GELU(v.x); v.y = DC_GELU(v.y); v.z = DC_GELU(v.z); v.w = DC_GELU(v.w);
-                }
-                uint2 pk;
-                pk.x = pack_bf2(v.x, v.y);
-                pk.y = pack_bf2(v.z, v.w);
-                *reinterpret_cast<uint2*>(ebuf + er * 128 + (((4 * c + eq) ^ (((er >> 1) & 7) << 1)) << 3)) = pk;
-            }
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int row = h * 8 + rrow;
-                u32x4_t d = *reinterpret_cast<const u32x4_t*>(ebuf + row * 128 + ((rc ^ ((row >> 1) & 7)) << 4));
-                if constexpr (EPI == 1) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        d[e] = pack_bf2(__uint_as_float(d[e] << 16) + __uint_as_float(rr[h][e] << 16),
-                                        __uint_as_float(d[e] & 0xffff0000u) + __uint_as_float(rr[h][e] & 0xffff0000u));
-                }
-#ifndef PP_DBG_NO_STORE
-                if (rok[h]) *reinterpret_cast<u32x4_t*>(cbase + co[h]) = d;
-#else
-                if (rok[h] && d[0] == 0x12345678u) *reinterpret_cast<u32x4_t*>(cbase + co[h]) = d;
-#endif
-            }
-            __builtin_amdgcn_sched_barrier(0);
+        for (int h = 0; h < 2; ++h) {
+            int mr = m0 + wave * 64 + rb * 16 + h * 8 + rrow;
+            rok[h] = mr < p.M;
+            if (!rok[h]) mr = p.M - 1;                      // clamped rows are computed, never stored
+            co[h] = ((unsigned)mr * (unsigned)p.ldc + (unsigned)(n0 + rc * 8)) * 2u;
         }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            float4 v = make_float4(acc[rb][c][0] + bv[c].x, acc[rb][c][1] + bv[c].y, acc[rb][c][2] + bv[c].z, acc[rb][c][3] + bv[c].w);
+            v.x *= DC_GELU(acc[rb][c + 4][0] + bg[c].x); v.y *= DC_GELU(acc[rb][c + 4][1] + bg[c].y);
+            v.z *= DC_GELU(acc[rb][c + 4][2] + bg[c].z); v.w *= DC_GELU(acc[rb][c + 4][3] + bg[c].w);
+            uint2 pk;
+            pk.x = pack_bf2(v.x, v.y);
+            pk.y = pack_bf2(v.z, v.w);
+            *reinterpret_cast<uint2*>(ebuf + er * 128 + (((4 * c + eq) ^ (((er >> 1) & 7) << 1)) << 3)) = pk;
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int row = h * 8 + rrow;
+            const u32x4_t d = *reinterpret_cast<const u32x4_t*>(ebuf + row * 128 + ((rc ^ ((row >> 1) & 7)) << 4));
+#ifndef PP_DBG_NO_STORE
+            if (rok[h]) *reinterpret_cast<u32x4_t*>(cbase + co[h]) = d;
+#else
+            if (rok[h] && d[0] == 0x12345678u) *reinterpret_cast<u32x4_t*>(cbase + co[h]) = d;
+#endif
+        }
+        __builtin_amdgcn_sched_barrier(0);
     }
 }
 
 inline bool pp_ok(const DcGemmParams& p) {
-    const bool geglu = (p.flags & DC_GEMM_GEGLU) != 0;
-    if (p.mode != 0 || (p.flags & DC_GEMM_OUT_F32) || p.rowvec || p.alpha != 1.0f) return false;
-    if (geglu && p.residual) return false;
-    const int n_out = geglu ? p.N / 2 : p.N;
-    if (p.K % PP_K != 0 || p.K < 2 * PP_K || n_out % (geglu ? 64 : 128) != 0 || p.n_pad < p.N) return false;
+    if (!(p.flags & DC_GEMM_GEGLU) || (p.flags & (DC_GEMM_OUT_F32 | DC_GEMM_GELU)) || p.mode != 0 || p.rowvec || p.residual || p.alpha != 1.0f) return false;
+    const int n_out = p.N / 2;
+    if (p.K % PP_K != 0 || p.K < 2 * PP_K || n_out % 64 != 0 || p.n_pad < p.N) return false;
     if (p.lda % 8 != 0 || ((uintptr_t)p.A % 16) != 0 || (long long)p.M * p.lda * 2 >= (1ll << 31)) return false;
     if (p.ldc % 8 != 0 || ((uintptr_t)p.C % 16) != 0 || (long long)p.M * p.ldc * 2 >= (1ll << 32)) return false;
-    if (p.residual && (p.ldr % 8 != 0 || ((uintptr_t)p.residual % 16) != 0 || (long long)p.M * p.ldr * 2 >= (1ll << 32))) return false;
     if ((long long)p.N * p.K * 2 >= (1ll << 32)) return false;
     if (p.bias && ((uintptr_t)p.bias % 16) != 0) return false;
     return true;
 }
 
-template <bool GEGLU, int EPI>
 int launch_pp(const DcGemmParams& p, hipStream_t stream) {
     static DcLdsOnce lds_once;
-    if (const int e = lds_once.ensure(reinterpret_cast<const void*>(&gemm_pp_kernel<GEGLU, EPI>), PP_LDS)) return e;
-    const int n_out = GEGLU ? p.N / 2 : p.N;
+    if (const int e = lds_once.ensure(reinterpret_cast<const void*>(&gemm_pp_kernel), PP_LDS)) return e;
     GemmSplit sp;
     sp.partial = nullptr; sp.splits = 1; sp.tile_begin = 0;
-    sp.tile_count = ((p.M + GBM - 1) / GBM) * (n_out / (GEGLU ? 64 : 128));
+    sp.tile_count = ((p.M + GBM - 1) / GBM) * ((p.N / 2) / 64);
     sp.err = dc_error_word_device();
     if (!sp.err) return DC_ERR_ARG;
-    dc_note_variant(GEGLU ? "gemm_pp_kernel<geglu>" : EPI == 1 ? "gemm_pp_kernel<residual>" : "gemm_pp_kernel");
-    hipLaunchKernelGGL((gemm_pp_kernel<GEGLU, EPI>), dim3(sp.tile_count), dim3(256), PP_LDS, stream, p, sp, 8);
+    dc_note_variant("gemm_pp_kernel<geglu>");
+    hipLaunchKernelGGL(gemm_pp_kernel, dim3(sp.tile_count), dim3(256), PP_LDS, stream, p, sp, 8);
     DC_CHECK_LAUNCH();
     return 0;
 }
