@@ -377,7 +377,7 @@ def main():
                 rows.append(r)
             roof["per_kernel_eager_step"] = rows
             if os.environ.get("DC_BENCH_DETAIL"):
-                for (name, tag), v in sorted(tr.detail.items(), key=lambda kv: -kv[1]["ms"])[:40]:
+                for (name, tag), v in sorted(tr.detail.items(), key=lambda kv: -kv[1]["ms"])[:int(os.environ.get("DC_BENCH_DETAIL_N", "40"))]:
                     log(f"  {name:22s} mode,M,N,K={tag}  x{v['launches']:3d}  {v['ms']:8.3f} ms  "
                         f"{v['flops'] / (v['ms'] * 1e-3) / 1e12:7.1f} TF/s")
             dom = rows[0]

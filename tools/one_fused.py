@@ -1,5 +1,5 @@
 """Run ONE fused level-0 kernel a few times (for rocprofv3 --pmc passes through tools/pmc_one_gemm.sh with
-PMC_SCRIPT=one_fused.py). usage: one_fused.py ff | tconv | lnlin | linres | tattn   [rows]"""
+PMC_SCRIPT=one_fused.py). usage: one_fused.py ff | tconv | lnlin | linres | tattn | tattn640   [rows]"""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from dynamicrafter_amd import ops
@@ -34,6 +34,13 @@ elif which == "tattn":
     pwq = ops.PackedWeight.linear(torch.randn(960, 320, generator=g) * 320 ** -0.5, None, DEV)
     o = torch.empty_like(h)
     fn = lambda: ops.ln_qkv_temporal_attn320(h, (gam, bet), pwq, o, B=Bc, T=T, HW=HW, scale=0.125)
+elif which == "tattn640":                     # level 1: dim 640, M / 4 rows
+    M4 = M // 4
+    h6 = torch.randn(M4, 640, device=DEV).to(torch.bfloat16)
+    pwq = ops.PackedWeight.linear(torch.randn(1920, 640, generator=g) * 640 ** -0.5, None, DEV)
+    o = torch.empty_like(h6)
+    g6 = torch.ones(640, device=DEV); b6 = torch.zeros(640, device=DEV)
+    fn = lambda: ops.ln_qkv_temporal_attn(h6, (g6, b6), pwq, o, B=Bc, T=T, HW=M4 // 32, scale=0.125)
 else:
     raise SystemExit(f"unknown kernel {which}")
 for _ in range(3): fn()
