@@ -35,6 +35,10 @@ SHAPES = [
     ("conv3x3 1920->640 36x64", "conv", (36, 64), 1920, 640),
     ("conv3x3 640->1280 18x32", "conv", (18, 32), 640, 1280),
     ("conv3x3 1920->1280 18x32", "conv", (18, 32), 1920, 1280),
+    ("down3x3 s2 320 72x128", "down", (72, 128), 320, 320),
+    ("down3x3 s2 640 36x64", "down", (36, 64), 640, 640),
+    ("down3x3 s2 1280 18x32", "down", (18, 32), 1280, 1280),
+    ("lin 1280x1280 L3", "lin", 4608, 1280, 1280),
     ("tconv 640 36x64", "tconv", (36, 64), 640, 640),
     ("lin 2560->1280 L2", "lin", 18432, 2560, 1280),
     ("lin 5120->1280 L2", "lin", 18432, 5120, 1280),
@@ -60,6 +64,14 @@ def main():
             out = torch.empty(M, co // 2 if kind == "geglu" else co, dtype=torch.bfloat16, device=DEV)
             kw = dict(geglu=(kind == "geglu"))
             flops = 2.0 * M * co * ci
+        elif kind == "down":                         # Downsample: 3x3, stride 2, pad 1 (input H x W -> H/2 x W/2)
+            H, W = m
+            Mi, M = F * H * W, F * (H // 2) * (W // 2)
+            x = torch.randn(Mi, ci, device=DEV).to(torch.bfloat16)
+            pw = PackedWeight.conv3x3(torch.randn(co, ci, 3, 3) * (9 * ci) ** -0.5, torch.randn(co), DEV)
+            out = torch.empty(M, co, dtype=torch.bfloat16, device=DEV)
+            kw = dict(conv=dict(IH=H, IW=W, OH=H // 2, OW=W // 2, stride=2, pad=1, ups=0))
+            flops = 2.0 * M * co * ci * 9
         elif kind == "conv":
             H, W = m
             M = F * H * W
