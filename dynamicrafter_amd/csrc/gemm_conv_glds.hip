@@ -66,6 +66,11 @@ struct GemmSplit {
     int tile_begin;
     int tile_count;
     int* err;          // the library's error word (dc_common.h); set by the launchers of kernels with bounded counter waits
+    // gemm_pipe320x16_kernel only - the "whole waves + split remainder" plan as ONE launch (1-D grid): the first `whole` workgroups
+    // compute the tiles [0, whole) with the normal epilogue, workgroup whole + s * tile_count + i computes K range s of tile
+    // tile_begin + i into `partial`. The hardware hands out workgroups in order, so a CU that finishes its whole tile picks up a
+    // K range at once instead of idling to the end of the launch (one launch boundary less per conv). 0: classic launch.
+    int whole;
 };
 
 template <int BN, bool GEGLU, int MODE, int GSTAGES>
@@ -936,7 +941,7 @@ int launch_glds(const DcGemmParams& p, hipStream_t stream) {
     static DcLdsOnce lds_once;
     if (const int e = lds_once.ensure(reinterpret_cast<const void*>(&gemm_conv_glds_kernel<BN, GEGLU, MODE, GSTAGES>), (int)lds)) return e;
     GemmSplit sp;
-    sp.partial = nullptr; sp.splits = 1; sp.tile_begin = 0; sp.tile_count = tiles_m * tiles_n; sp.err = nullptr;
+    sp.partial = nullptr; sp.splits = 1; sp.tile_begin = 0; sp.tile_count = tiles_m * tiles_n; sp.err = nullptr; sp.whole = 0;
     dc_note_variant(GEGLU ? "gemm_conv_glds_kernel<geglu>"
                     : BN == 320 ? (MODE == 0 ? "gemm_conv_glds_kernel<320>" : MODE == 2 ? "gemm_conv_glds_kernel<320,tconv>" : "gemm_conv_glds_kernel<320,conv>")
                     : BN == 256 ? (MODE == 0 ? "gemm_conv_glds_kernel<256>" : MODE == 2 ? "gemm_conv_glds_kernel<256,tconv>" : "gemm_conv_glds_kernel<256,conv>")
@@ -953,9 +958,10 @@ int launch_glds(const DcGemmParams& p, hipStream_t stream) {
 // persistent kernels. Bit 3 of older plan values (9 / 11) is accepted and dropped.
 // bit 4 (16): the ping-pong kernel (gemm_pp.h: 4-wave workgroups, two per CU) for the GEGLU projections with K <= 640 and
 // >= 1024 tiles; bit 5 (32): without the K limit (tests, A/B).
+// bit 6 (64): the "whole waves + split remainder" plans as two launches (round 3's form) instead of one (GemmSplit::whole): tests, A/B.
 constexpr int PLAN_DEFAULT = 3 | 16;
-constexpr int PLAN_MASK = 3 | 16 | 32;
-inline bool plan_valid(int plan) { return plan >= 0 && plan <= 63 && !(plan & 4); }
+constexpr int PLAN_MASK = 3 | 16 | 32 | 64;
+inline bool plan_valid(int plan) { return plan >= 0 && plan <= 127 && !(plan & 4); }
 std::atomic<int> g_gemm_plan{[] {
     const char* e = getenv("DC_GEMM_PLAN");
     const int v = e ? atoi(e) : PLAN_DEFAULT;
@@ -990,7 +996,7 @@ inline bool pipe_ok(const DcGemmParams& p, int plan) {
 int launch_pipe_whole(const DcGemmParams& p, hipStream_t stream) {
     const int ntiles = ((p.M + GBM - 1) / GBM) * (p.N / 320);
     GemmSplit sp;
-    sp.partial = nullptr; sp.splits = 1; sp.tile_begin = 0; sp.tile_count = ntiles; sp.err = nullptr;
+    sp.partial = nullptr; sp.splits = 1; sp.tile_begin = 0; sp.tile_count = ntiles; sp.err = nullptr; sp.whole = 0;
     dc_note_variant(p.mode == 0 ? "gemm_pipe320x16_kernel" : p.mode == 2 ? "gemm_pipe320x16_kernel<tconv>"
                     : p.ups ? "gemm_pipe320x16_kernel<conv,ups>" : "gemm_pipe320x16_kernel<conv>");
     if (p.mode == 0) return p.residual ? launch_pipe_shape<0, 1>(p, stream, sp, ntiles, 1) : launch_pipe_shape<0, 0>(p, stream, sp, ntiles, 1);
@@ -1002,7 +1008,7 @@ int launch_pipe_whole(const DcGemmParams& p, hipStream_t stream) {
 // 320-wide tiles with split-K: `full` leading tiles as whole tiles (0 = none), the remaining tiles cut into `splits`
 // K ranges + reduce. Partials: splits * (ntiles - full) * 256 * 320 floats of workspace.
 template <int MODE>
-int launch_glds320_split(const DcGemmParams& p, hipStream_t stream, int ntiles, int full, int splits, bool use_pipe) {
+int launch_glds320_split(const DcGemmParams& p, hipStream_t stream, int ntiles, int full, int splits, bool use_pipe, bool merged) {
     constexpr int BN = 320, GSTAGES = 2;
     constexpr size_t lds = (size_t)GSTAGES * (GBM * GBK * 2 + BN * GBK * 2);
     static DcLdsOnce lds_once;
@@ -1012,13 +1018,22 @@ int launch_glds320_split(const DcGemmParams& p, hipStream_t stream, int ntiles, 
             dc_note_variant(MODE == 0 ? "gemm_pipe320x16_kernel+splitk" : MODE == 2 ? "gemm_pipe320x16_kernel<tconv>+splitk"
                             : MODE == 3 ? "gemm_pipe320x16_kernel<conv,ups>+splitk" : "gemm_pipe320x16_kernel<conv>+splitk");
             GemmSplit sp;
-            sp.err = nullptr;
-            if (full > 0) {
-                sp.partial = nullptr; sp.splits = 1; sp.tile_begin = 0; sp.tile_count = full;
-                if (const int e = p.residual ? launch_pipe_shape<MODE, 1>(p, stream, sp, full, 1) : launch_pipe_shape<MODE, 0>(p, stream, sp, full, 1)) return e;
+            sp.err = nullptr; sp.whole = 0;
+            if (full > 0 && merged && full % 8 == 0) {
+                // whole tiles and the K ranges of the remainder tiles in ONE launch (GemmSplit::whole)
+                sp.partial = reinterpret_cast<float*>(p.workspace); sp.splits = splits; sp.tile_begin = full; sp.tile_count = ntiles - full;
+                sp.whole = full;
+                const int gx = full + sp.tile_count * splits;
+                if (const int e = p.residual ? launch_pipe_shape<MODE, 1>(p, stream, sp, gx, 1) : launch_pipe_shape<MODE, 0>(p, stream, sp, gx, 1)) return e;
+                sp.whole = 0;
+            } else {
+                if (full > 0) {
+                    sp.partial = nullptr; sp.splits = 1; sp.tile_begin = 0; sp.tile_count = full;
+                    if (const int e = p.residual ? launch_pipe_shape<MODE, 1>(p, stream, sp, full, 1) : launch_pipe_shape<MODE, 0>(p, stream, sp, full, 1)) return e;
+                }
+                sp.partial = reinterpret_cast<float*>(p.workspace); sp.splits = splits; sp.tile_begin = full; sp.tile_count = ntiles - full;
+                if (const int e = launch_pipe_shape<MODE, 0>(p, stream, sp, sp.tile_count, splits)) return e;
             }
-            sp.partial = reinterpret_cast<float*>(p.workspace); sp.splits = splits; sp.tile_begin = full; sp.tile_count = ntiles - full;
-            if (const int e = launch_pipe_shape<MODE, 0>(p, stream, sp, sp.tile_count, splits)) return e;
             hipLaunchKernelGGL((splitk_reduce_kernel<BN>), dim3((GBM * (BN / 4) + 255) / 256, sp.tile_count), dim3(256), 0, stream, p, sp);
             DC_CHECK_LAUNCH();
             return 0;
@@ -1026,7 +1041,7 @@ int launch_glds320_split(const DcGemmParams& p, hipStream_t stream, int ntiles, 
     }
     dc_note_variant(MODE == 0 ? "gemm_conv_glds_kernel<320>+splitk" : MODE == 2 ? "gemm_conv_glds_kernel<320,tconv>+splitk" : "gemm_conv_glds_kernel<320,conv>+splitk");
     GemmSplit sp;
-    sp.err = nullptr;
+    sp.err = nullptr; sp.whole = 0;
     if (full > 0) {
         sp.partial = nullptr; sp.splits = 1; sp.tile_begin = 0; sp.tile_count = full;
         hipLaunchKernelGGL((gemm_conv_glds_kernel<BN, false, MODE, GSTAGES>), dim3(full), dim3(GNT), lds, stream, p, sp);
@@ -1119,9 +1134,12 @@ int dc_gemm_conv_glds_try(const DcGemmParams& p, hipStream_t stream) {
     const int w320 = n320 ? tiles_m * (p.N / 320) : 0;
     const int w128 = tiles_m * t128;
     const float waste128 = (float)(t128 * 128) / (float)p.N;
-    float s320 = n320 ? 1.25f * wave_eff(w320) : 0.f;
+    // (3x3 convs on the one-wave kernel: 1.4x, and down to 128 tiles - the level-1 -> 2 Downsample conv [18432 x 640 x 5760], 144
+    //  tiles, measured 168 us there against 224 us on the 128-row kernel, tools/gemm_bench.py --only down3x3)
+    const bool pipe_conv = use_pipe && p.mode == 1 && force == 0;
+    float s320 = n320 ? (pipe_conv ? 1.4f : 1.25f) * wave_eff(w320) : 0.f;
     float s128 = wave_eff(w128) / waste128;
-    if (w320 < 200) s320 = 0.f;
+    if (w320 < (pipe_conv ? 128 : 200)) s320 = 0.f;
     if (w128 < 384) s128 = 0.f;
     // split-K plans for the 320-wide tile (needs the caller's workspace)
     static const int splitk = [] { const char* e = getenv("DC_GEMM_SPLITK"); return e ? atoi(e) : 1; }();
@@ -1143,10 +1161,11 @@ int dc_gemm_conv_glds_try(const DcGemmParams& p, hipStream_t stream) {
         }
         const size_t need = (size_t)splits * (size_t)(w320 - full) * GBM * 320 * sizeof(float);
         if (splits >= 2 && nk / splits >= (full ? 8 : 12) && need <= (size_t)p.workspace_bytes) {
-            if (p.mode == 0) return launch_glds320_split<0>(p, stream, w320, full, splits, use_pipe);
-            if (p.mode == 1) return p.ups ? launch_glds320_split<3>(p, stream, w320, full, splits, use_pipe)
-                                          : launch_glds320_split<1>(p, stream, w320, full, splits, use_pipe);
-            return launch_glds320_split<2>(p, stream, w320, full, splits, use_pipe);
+            const bool merged = !(plan & 64);
+            if (p.mode == 0) return launch_glds320_split<0>(p, stream, w320, full, splits, use_pipe, merged);
+            if (p.mode == 1) return p.ups ? launch_glds320_split<3>(p, stream, w320, full, splits, use_pipe, merged)
+                                          : launch_glds320_split<1>(p, stream, w320, full, splits, use_pipe, merged);
+            return launch_glds320_split<2>(p, stream, w320, full, splits, use_pipe, merged);
         }
     }
     if (force == 320 && n320) return use_pipe ? launch_pipe_whole(p, stream) : launch_glds_mode<320, 2>(p, stream);

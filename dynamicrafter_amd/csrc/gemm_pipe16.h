@@ -39,15 +39,22 @@ void gemm_pipe320x16_kernel(const DcGemmParams p, const GemmSplit sp) {
     const int lr = lane & 15, lq = lane >> 4;
 
     const int tiles_n = p.N / 320;
-    const int swz = sp.tile_begin + xcd_remap(blockIdx.x, sp.tile_count);
+    // which tile, which K range, which epilogue: the launch's (classic), or per workgroup under the merged plan (GemmSplit::whole)
+    int bx = blockIdx.x, by = blockIdx.y, tile_begin = sp.tile_begin, tile_count = sp.tile_count, nsplit = sp.splits;
+    float* partial = sp.partial;
+    if (sp.whole > 0) {
+        if (bx < sp.whole) { tile_begin = 0; tile_count = sp.whole; nsplit = 1; partial = nullptr; by = 0; }
+        else { bx -= sp.whole; by = bx / tile_count; bx -= by * tile_count; }
+    }
+    const int swz = tile_begin + xcd_remap(bx, tile_count);
     const int tile_n = swz % tiles_n;
     const int tile_m = swz / tiles_n;
     const int m0 = tile_m * GBM;
     const int n0 = tile_n * 320;
 
     const int nk_all = p.K / GBK;
-    const int kt_lo = (int)(((long long)blockIdx.y * nk_all) / sp.splits);
-    const int kt_hi = (int)(((long long)(blockIdx.y + 1) * nk_all) / sp.splits);
+    const int kt_lo = (int)(((long long)by * nk_all) / nsplit);
+    const int kt_hi = (int)(((long long)(by + 1) * nk_all) / nsplit);
     const int nk = kt_hi - kt_lo;
 
     gp_lds_int_t* const cnt_landed = (gp_lds_int_t*)(smem + GP_CNT);
@@ -319,10 +326,10 @@ void gemm_pipe320x16_kernel(const DcGemmParams p, const GemmSplit sp) {
 #endif
 
     // ---- epilogue. A lane holds, of output row 16 rb + lr, the channels 16 cb + 4 lq .. + 3 of every column block.
-    if (sp.partial) {
+    if (partial) {
         // split-K: raw fp32 accumulators, [split][tile][256][320]; splitk_reduce_kernel applies the epilogue
-        const size_t slot = (size_t)blockIdx.y * sp.tile_count + (size_t)(swz - sp.tile_begin);
-        float* const dst = sp.partial + (slot * GBM + wave * 64 + lr) * 320 + 4 * lq;
+        const size_t slot = (size_t)by * tile_count + (size_t)(swz - tile_begin);
+        float* const dst = partial + (slot * GBM + wave * 64 + lr) * 320 + 4 * lq;
 #pragma unroll
         for (int rb = 0; rb < 4; ++rb)
 #pragma unroll

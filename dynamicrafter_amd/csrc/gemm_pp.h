@@ -307,7 +307,7 @@ int launch_pp(const DcGemmParams& p, hipStream_t stream) {
     static DcLdsOnce lds_once;
     if (const int e = lds_once.ensure(reinterpret_cast<const void*>(&gemm_pp_kernel), PP_LDS)) return e;
     GemmSplit sp;
-    sp.partial = nullptr; sp.splits = 1; sp.tile_begin = 0;
+    sp.partial = nullptr; sp.splits = 1; sp.tile_begin = 0; sp.whole = 0;
     sp.tile_count = ((p.M + GBM - 1) / GBM) * ((p.N / 2) / 64);
     sp.err = dc_error_word_device();
     if (!sp.err) return DC_ERR_ARG;

@@ -699,6 +699,42 @@ def test_conv3x3_pipe_plans(ops, gemm_plan, cfg, res):
     assert torch.equal(outs[0], outs[1])                             # fixed summation order: bitwise reproducible
 
 
+# ---- "whole waves + split remainder" as ONE launch (GemmSplit::whole, the default) against the two-launch form (plan bit 6):
+# the same tiles, K ranges and summation order, so the outputs are bit-identical
+@pytest.mark.parametrize("cfg,res", [PIPE_CONVS[1], PIPE_CONVS[2],
+                                     (dict(n=32, C=640, Co=640, H=18, W=32, stride=1, pad=1, ups=1), False)])
+def test_pipe_merged_split_launch_bitwise(ops, cfg, res):
+    lib = ops._hip.lib()
+    n, C, Co, H, W, ups = (cfg[k] for k in ("n", "C", "Co", "H", "W", "ups"))
+    OH, OW = (2 * H, 2 * W) if ups else (H, W)
+    g = torch.Generator(device=DEV).manual_seed(11)
+    x = torch.randn(n, C, H, W, device=DEV, generator=g).to(torch.bfloat16)
+    w = torch.randn(Co, C, 3, 3, device=DEV, generator=g) * (9 * C) ** -0.5
+    b = torch.randn(Co, device=DEV, generator=g)
+    r = torch.randn(n * OH * OW, Co, device=DEV, generator=g).to(torch.bfloat16) if res else None
+    xin = F.interpolate(x.float(), scale_factor=2, mode="nearest") if ups else x.float()
+    ref = F.conv2d(xin, w.to(torch.bfloat16).float(), b, padding=1).permute(0, 2, 3, 1).reshape(-1, Co)
+    if res:
+        ref = ref.to(torch.bfloat16).float() + r.float()
+    pw = ops.PackedWeight.conv3x3(w.cpu(), b.cpu(), DEV)
+    rows = x.permute(0, 2, 3, 1).reshape(-1, C).contiguous()
+    outs = {}
+    for plan in (19, 19 | 64):
+        prev = lib.dc_gemm_set_plan(plan)
+        assert prev >= 0
+        try:
+            out = torch.empty(n * OH * OW, Co, dtype=torch.bfloat16, device=DEV)
+            ops.gemm(rows, pw, out, conv=dict(IH=H, IW=W, OH=OH, OW=OW, stride=1, pad=1, ups=ups), residual=r)
+            assert "gemm_pipe320x16" in _variant(ops) and "+splitk" in _variant(ops), _variant(ops)
+            outs[plan] = out
+        finally:
+            lib.dc_gemm_set_plan(prev)
+    assert rel_l2(outs[19], ref) < 4e-3
+    assert torch.equal(outs[19], outs[19 | 64])
+    torch.cuda.synchronize()
+    ops._hip.check_error_word("merged split launch")
+
+
 @pytest.mark.parametrize("gemm_plan", [3, 0], indirect=True)
 @pytest.mark.parametrize("cfg", [
     dict(n=32, C=1280, Co=1280, H=9, W=16, stride=1, pad=1, ups=1),          # level 3 -> 2 Upsample: 72 tiles, split-K
