@@ -98,11 +98,11 @@ def make_clip_inputs(res, n_clips, seed=7):
                 fs=torch.full((n_clips,), 10, dtype=torch.int64))
 
 
-def distribute_inputs(res, world, rank, coll_dev):
+def distribute_inputs(res, world, rank, coll_dev, use_dist=None):
     """Rank 0 builds all clips' conditioning and scatters one clip to every rank (parallel.scatter_conditioning: one
     metadata broadcast + one scatter per tensor). Same code on RCCL (`coll_dev` = the rank's GPU) and on gloo (CPU)."""
     from dynamicrafter_amd.parallel import scatter_conditioning
-    if world == 1:
+    if not (world > 1 if use_dist is None else use_dist):
         return make_clip_inputs(res, 1)
     full = None
     if rank == 0:
@@ -192,7 +192,16 @@ def main():
     dev_index = 0 if os.environ.get("DC_BENCH_SHARE_GPU") == "1" else local_rank
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
-    if world > 1:
+    # DC_BENCH_FORCE_DIST=1: take the N>1 code path (process group, scatter, barriers, max / gather of the timings) with ONE rank -
+    # on a one-GPU box this is the only way RCCL itself executes this job's collectives (tests/test_model_gpu.py)
+    use_dist = world > 1 or os.environ.get("DC_BENCH_FORCE_DIST") == "1"
+    if use_dist and world == 1 and "MASTER_ADDR" not in os.environ:
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1")
+    if use_dist:
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=device)
         else:
@@ -211,8 +220,8 @@ def main():
     T, S = T_FRAMES, S_STEPS
     # ---- conditioning: rank 0 -> every rank, one clip each (the only inter-GPU traffic of the job)
     t_sc = time.perf_counter()
-    inp = distribute_inputs(res, world, rank, coll_dev)
-    if world > 1:
+    inp = distribute_inputs(res, world, rank, coll_dev, use_dist)
+    if use_dist:
         if backend == "nccl":
             torch.cuda.synchronize()
         dist.barrier()
@@ -243,7 +252,7 @@ def main():
     do_steps(args.warmup, 0)
     run.sync()
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     e0, e1 = C.c_void_p(), C.c_void_p()
     l.dc_event_create(C.byref(e0)); l.dc_event_create(C.byref(e1))
@@ -253,13 +262,13 @@ def main():
     l.dc_event_record(e1, run.graph._stream)
     run.sync()
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     elapsed = time.perf_counter() - t0
     ev_ms = C.c_float()
     l.dc_event_elapsed_ms(e0, e1, C.byref(ev_ms))
     my_step_ms = ev_ms.value / args.steps                        # this rank's own step time (HIP events on its stream)
-    if world > 1:
+    if use_dist:
         tt = torch.tensor([elapsed], device=coll_dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = tt.item()
@@ -297,7 +306,7 @@ def main():
     my_clip_s = S * my_step_ms / 1e3 + ((enc_ms or 0) + (dec_ms or 0)) / 1e3
     clip_s = S * ms_per_step / 1e3 + ((enc_ms or 0) + (dec_ms or 0)) / 1e3
     per_rank = [dict(rank=rank, step_ms=round(my_step_ms, 3), clip_seconds=round(my_clip_s, 3))]
-    if world > 1:
+    if use_dist:
         stats = torch.tensor([my_step_ms, my_clip_s, clip_s], device=coll_dev, dtype=torch.float64)
         allst = [torch.zeros_like(stats) for _ in range(world)]
         dist.all_gather(allst, stats)
@@ -322,12 +331,12 @@ def main():
         "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "bf16", "data": "synthetic (random-init weights, synthetic conditioning)",
         "peak_mem_gb": round(peak_mem_gb, 2),
-        "n_ranks_seen": dist.get_world_size() if world > 1 else 1, "backend": backend if world > 1 else None,
+        "n_ranks_seen": dist.get_world_size() if use_dist else 1, "backend": backend if use_dist else None,
         "config": {"workload": f"inference_{res}_v1.0.yaml: 1 clip/GPU, 16 frames, latent {h}x{w}, DDIM 50 "
                                "uniform_trailing eta=1, CFG 7.5 batched (cond+uncond), guidance_rescale 0.7, "
                                "v-param+ZTSNR+dynamic rescale, hipGraph-captured step",
                    "clips_per_gpu": 1, "parallelism": f"dp{world} over {world} distinct clips (no data-path collective)",
-                   "conditioning": ("local (1 rank)" if world == 1 else
+                   "conditioning": ("local (1 rank)" if not use_dist else
                                     f"scatter_conditioning from rank 0 over {backend} ({dist.get_world_size()} ranks), "
                                     f"{scatter_ms:.1f} ms incl. rank-0 synthesis"),
                    "per_rank": per_rank,
@@ -419,7 +428,7 @@ def main():
                 raise SystemExit(f"bench: HIP output does not match the oracle (rel-L2 {rel:.3e} >= {PARITY_TOL}) "
                                  f"or is not finite - the timing above is not a valid result")
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

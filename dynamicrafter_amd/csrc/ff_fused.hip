@@ -66,18 +66,20 @@ __device__ unsigned long long g_ff_stamps[8];
 #define FF_STAMP(i) do { } while (0)
 #endif
 
+#ifdef DC_FF_GELU_ERF
+#define FF_GELU(x) gelu_erf_f(x)
+#else
+#define FF_GELU(x) gelu_phi_f(x)      // the last chunk's stand-alone GEGLU: the same function as the interleaved stream
+#endif
 __device__ __forceinline__ int off128(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
 __device__ __forceinline__ int off64(int row, int chunk) { return row * 64 + ((chunk ^ ((row >> 2) & 3)) << 4); }
 
 __device__ __forceinline__ void glds16f(const void* gsrc, unsigned lds_dst_uniform) {
-    unsigned keep;
     asm volatile(
-        "s_mov_b32 %0, m0\n\t"
-        "s_mov_b32 m0, %2\n\t"
+        "s_mov_b32 m0, %1\n\t"
         "s_nop 0\n\t"
-        "global_load_lds_dwordx4 %1, off\n\t"
-        "s_mov_b32 m0, %0"
-        : "=&s"(keep)
+        "global_load_lds_dwordx4 %0, off"
+        :
         : "v"(gsrc), "s"(lds_dst_uniform)
         : "memory");
 }
@@ -218,14 +220,13 @@ void ff_geglu_fused320_kernel(const FfParams p) {
 #pragma unroll                                                       // in the main loop (5 scalar instructions per piece)
     for (int i = 0; i < 5; ++i) asm volatile("" : "+v"(vo2[i]));
     auto dma_piece = [&](unsigned lds_dst, unsigned voff, uint64_t sbase) __attribute__((always_inline)) {
-        unsigned keep;
+        // (m0 is NOT saved and restored around a piece: nothing else in these kernels uses it - checked in the ISA, as for gemm_pipe16.h - and
+        //  two scalar moves per piece are 8-10 issue clocks of a one-wave-per-SIMD stream)
         asm volatile(
-            "s_mov_b32 %0, m0\n\t"
-            "s_mov_b32 m0, %1\n\t"
+            "s_mov_b32 m0, %0\n\t"
             "s_nop 0\n\t"
-            "global_load_lds_dwordx4 %2, %3\n\t"
-            "s_mov_b32 m0, %0"
-            : "=&s"(keep)
+            "global_load_lds_dwordx4 %1, %2"
+            :
             : "s"(lds_dst), "v"(voff), "s"(sbase)
             : "memory");
     };
@@ -303,10 +304,10 @@ void ff_geglu_fused320_kernel(const FfParams p) {
                     const int n = c * FCH + 8 * q + 4 * fh;
                     const float4 bv = *reinterpret_cast<const float4*>(b1s + n);
                     const float4 bg = *reinterpret_cast<const float4*>(b1s + FM + n);
-                    const float v0 = (av[4 * q + 0] + bv.x) * gelu_erf_f(ag[4 * q + 0] + bg.x);
-                    const float v1 = (av[4 * q + 1] + bv.y) * gelu_erf_f(ag[4 * q + 1] + bg.y);
-                    const float v2 = (av[4 * q + 2] + bv.z) * gelu_erf_f(ag[4 * q + 2] + bg.z);
-                    const float v3 = (av[4 * q + 3] + bv.w) * gelu_erf_f(ag[4 * q + 3] + bg.w);
+                    const float v0 = (av[4 * q + 0] + bv.x) * FF_GELU(ag[4 * q + 0] + bg.x);
+                    const float v1 = (av[4 * q + 1] + bv.y) * FF_GELU(ag[4 * q + 1] + bg.y);
+                    const float v2 = (av[4 * q + 2] + bv.z) * FF_GELU(ag[4 * q + 2] + bg.z);
+                    const float v3 = (av[4 * q + 3] + bv.w) * FF_GELU(ag[4 * q + 3] + bg.w);
                     pw[2 * h2] = pack_bf2(v0, v1);
                     pw[2 * h2 + 1] = pack_bf2(v2, v3);
                 }
@@ -365,6 +366,9 @@ void ff_geglu_fused320_kernel(const FfParams p) {
             float4 bv = *reinterpret_cast<const float4*>(b1s + c * FCH + 4 * fh);
             float4 bg = *reinterpret_cast<const float4*>(b1s + FM + c * FCH + 4 * fh);
             float xg0, xg1, ww0, ww1;
+#ifndef DC_FF_GELU_ERF
+            float xc0, xc1, qq0, qq1;
+#endif
             u32x4_t pw[2];
 #pragma unroll
             for (int kk = 0; kk < FD / 16; ++kk) {
@@ -379,6 +383,7 @@ void ff_geglu_fused320_kernel(const FfParams p) {
                 // - 21 vector instructions per channel pair instead of 27 (this stream is issue-bound)
                 // (scalar f32 instructions on purpose: beside MFMAs a v_pk_fma_f32 costs ~22 cycles more than the two
                 // v_fma_f32 it replaces - MI355X_MICROARCH 'price of one filler' - and this stream is issue-bound)
+#ifdef DC_FF_GELU_ERF     // tool build (same-box A/B): the erf form of round 2 (Abramowitz-Stegun 7.1.26: v_rcp_f32 + v_exp_f32, 8 issue clocks each)
                 if (kk < 16 && !(kk & 1)) {               // polynomial half
                     float g0 = cg[2 * m], g1 = cg[2 * m + 1];
                     asm volatile("" : "+v"(g0), "+v"(g1));
@@ -414,6 +419,45 @@ void ff_geglu_fused320_kernel(const FfParams p) {
                     if ((kk & 3) == 3 && kk < 12)
                         bv = *reinterpret_cast<const float4*>(b1s + c * FCH + 8 * ((kk >> 2) + 1) + 4 * fh);
                 }
+#else
+                // gelu(x) = x Phi(x) with the clamped polynomial of the GEMM epilogues (phi_poly_f, dc_common.h: |error| <= 1.9e-4, below
+                // the bf16 rounding of P): per element 13.5 full-rate instructions (54 issue clocks) instead of 15.5 + v_rcp_f32 +
+                // v_exp_f32 (78) - this stream is issue-bound. Even steps: clamp, square, the first three Horner steps of the pair;
+                // odd steps: the other three, Phi, the GEGLU product and the bf16 pack.
+                if (kk < 16 && !(kk & 1)) {
+                    float g0 = cg[2 * m], g1 = cg[2 * m + 1];
+                    asm volatile("" : "+v"(g0), "+v"(g1));
+                    xg0 = g0 + ((m & 1) ? bg.z : bg.x);
+                    xg1 = g1 + ((m & 1) ? bg.w : bg.y);
+                    xc0 = __builtin_amdgcn_fmed3f(xg0, -4.0f, 4.0f);
+                    xc1 = __builtin_amdgcn_fmed3f(xg1, -4.0f, 4.0f);
+                    ww0 = xc0 * xc0;
+                    ww1 = xc1 * xc1;
+                    float q0 = fmaf(2.258878772920525e-08f, ww0, -1.5888579127931735e-06f);
+                    float q1 = fmaf(2.258878772920525e-08f, ww1, -1.5888579127931735e-06f);
+                    q0 = fmaf(q0, ww0, 4.776452260557562e-05f);   q1 = fmaf(q1, ww1, 4.776452260557562e-05f);
+                    q0 = fmaf(q0, ww0, -0.0008121939026750624f);  q1 = fmaf(q1, ww1, -0.0008121939026750624f);
+                    qq0 = q0; qq1 = q1;
+                    asm volatile("" : "+v"(qq0), "+v"(qq1), "+v"(ww0), "+v"(ww1), "+v"(xc0), "+v"(xc1), "+v"(xg0), "+v"(xg1));
+                    if ((kk & 3) == 2 && kk < 12)         // accumulator values 4 q .. 4 q + 3 are channels 8 q + 4 fh + i
+                        bg = *reinterpret_cast<const float4*>(b1s + FM + c * FCH + 8 * ((kk >> 2) + 1) + 4 * fh);
+                } else if (kk < 16) {
+                    float v0 = cv[2 * m], v1 = cv[2 * m + 1];
+                    asm volatile("" : "+v"(v0), "+v"(v1));
+                    v0 += (m & 1) ? bv.z : bv.x;
+                    v1 += (m & 1) ? bv.w : bv.y;
+                    float q0 = fmaf(qq0, ww0, 0.008763724006712437f), q1 = fmaf(qq1, ww1, 0.008763724006712437f);
+                    q0 = fmaf(q0, ww0, -0.06455449014902115f);  q1 = fmaf(q1, ww1, -0.06455449014902115f);
+                    q0 = fmaf(q0, ww0, 0.3978703022003174f);    q1 = fmaf(q1, ww1, 0.3978703022003174f);
+                    const float o0 = (xg0 * fmaf(xc0, q0, 0.5f)) * v0;
+                    const float o1 = (xg1 * fmaf(xc1, q1, 0.5f)) * v1;
+                    unsigned w = pack_bf2(o0, o1);
+                    asm volatile("" : "+v"(w));
+                    pw[m >> 2][m & 3] = w;
+                    if ((kk & 3) == 3 && kk < 12)
+                        bv = *reinterpret_cast<const float4*>(b1s + c * FCH + 8 * ((kk >> 2) + 1) + 4 * fh);
+                }
+#endif
                 ng = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fg, xf[kk], ng, 0, 0, 0);
                 asm volatile("" : "+a"(ng));
             }
@@ -687,14 +731,13 @@ void norm_linear_kernel(const LlParams p) {
         asm volatile("" : "+v"(vo[i]));
     }
     auto dma_piece = [&](unsigned lds_dst, unsigned voff, uint64_t sbase) __attribute__((always_inline)) {
-        unsigned keep;
+        // (m0 is NOT saved and restored around a piece: nothing else in these kernels uses it - checked in the ISA, as for gemm_pipe16.h - and
+        //  two scalar moves per piece are 8-10 issue clocks of a one-wave-per-SIMD stream)
         asm volatile(
-            "s_mov_b32 %0, m0\n\t"
-            "s_mov_b32 m0, %1\n\t"
+            "s_mov_b32 m0, %0\n\t"
             "s_nop 0\n\t"
-            "global_load_lds_dwordx4 %2, %3\n\t"
-            "s_mov_b32 m0, %0"
-            : "=&s"(keep)
+            "global_load_lds_dwordx4 %1, %2"
+            :
             : "s"(lds_dst), "v"(voff), "s"(sbase)
             : "memory");
     };
@@ -884,14 +927,13 @@ void ln_qkv_tattn_kernel(const TaParams p) {
         asm volatile("" : "+v"(vo[i]));
     }
     auto dma_piece = [&](unsigned lds_dst, unsigned voff, uint64_t sbase) __attribute__((always_inline)) {
-        unsigned keep;
+        // (m0 is NOT saved and restored around a piece: nothing else in these kernels uses it - checked in the ISA, as for gemm_pipe16.h - and
+        //  two scalar moves per piece are 8-10 issue clocks of a one-wave-per-SIMD stream)
         asm volatile(
-            "s_mov_b32 %0, m0\n\t"
-            "s_mov_b32 m0, %1\n\t"
+            "s_mov_b32 m0, %0\n\t"
             "s_nop 0\n\t"
-            "global_load_lds_dwordx4 %2, %3\n\t"
-            "s_mov_b32 m0, %0"
-            : "=&s"(keep)
+            "global_load_lds_dwordx4 %1, %2"
+            :
             : "s"(lds_dst), "v"(voff), "s"(sbase)
             : "memory");
     };
@@ -1125,14 +1167,13 @@ void gn_silu_tconv_kernel(const TcParams p) {
         asm volatile("" : "+v"(vo[i]));
     }
     auto dma_piece = [&](unsigned lds_dst, unsigned voff, uint64_t sbase) __attribute__((always_inline)) {
-        unsigned keep;
+        // (m0 is NOT saved and restored around a piece: nothing else in these kernels uses it - checked in the ISA, as for gemm_pipe16.h - and
+        //  two scalar moves per piece are 8-10 issue clocks of a one-wave-per-SIMD stream)
         asm volatile(
-            "s_mov_b32 %0, m0\n\t"
-            "s_mov_b32 m0, %1\n\t"
+            "s_mov_b32 m0, %0\n\t"
             "s_nop 0\n\t"
-            "global_load_lds_dwordx4 %2, %3\n\t"
-            "s_mov_b32 m0, %0"
-            : "=&s"(keep)
+            "global_load_lds_dwordx4 %1, %2"
+            :
             : "s"(lds_dst), "v"(voff), "s"(sbase)
             : "memory");
     };

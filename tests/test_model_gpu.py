@@ -634,6 +634,31 @@ def test_bench_gpus_2_launches_itself():
     assert out["config"]["outputs_finite"] and len(out["config"]["per_rank"]) == 2
 
 
+def test_bench_one_rank_over_rccl():
+    """The collectives of the N > 1 job on RCCL itself: `DC_BENCH_FORCE_DIST=1` makes a one-rank bench.py take the N > 1 code path
+    with backend "nccl" (= RCCL) - init_process_group(device_id=), broadcast_object_list + dist.scatter of device tensors
+    (parallel.scatter_conditioning), barriers, all_reduce(MAX) and all_gather of the timings on the GPU. A one-GPU box cannot host
+    two RCCL ranks; with one rank every call still goes through RCCL's API and stream semantics (an argument RCCL rejects, or a
+    collective issued on the wrong device, fails here and not first on the 8-GPU node). 256 config, 2 steps."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.join(os.path.dirname(G), "..")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT",
+                                                             "DC_BENCH_BACKEND", "DC_BENCH_SHARE_GPU")}
+    env.update(DC_BENCH_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1",
+                        "--res", "256", "--no-ae", "--no-trace", "--no-cpu-baseline"], capture_output=True, text=True,
+                       env=env, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(line) == 1
+    out = json.loads(line[0])
+    assert out["n_gpus"] == 1 and out["n_ranks_seen"] == 1 and out["backend"] == "nccl"
+    assert "scatter_conditioning from rank 0 over nccl" in out["config"]["conditioning"]
+    assert out["config"]["outputs_finite"] and len(out["config"]["per_rank"]) == 1
+
+
 def test_ae_frames_per_call_keeps_per_frame_results():
     """`perframe_ae`: the reference calls the AutoencoderKL once per frame (ddpm3d.py:633-639,657-663); here several
     frames ride one launch sequence (GroupNorm / mid attention are per frame, so only the rows per kernel change).

@@ -13,7 +13,8 @@ FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -I$ROOT/include -I$CS $FL"
 OBJS=()
 for f in $SRCS; do
   case " $* " in
-    *" $f "*) /opt/rocm/bin/hipcc $FLAGS -c "$CS/$f.hip" -o "$OUT/obj_$NAME/$f.o" & OBJS+=("$OUT/obj_$NAME/$f.o") ;;
+    *" $f "*) PF=""; [ "$f" = ff_fused ] && [ -z "${DC_VARIANT_SLP:-}" ] && PF="-fno-slp-vectorize"      # the product's per-file flag (build.sh)
+              /opt/rocm/bin/hipcc $FLAGS $PF -c "$CS/$f.hip" -o "$OUT/obj_$NAME/$f.o" & OBJS+=("$OUT/obj_$NAME/$f.o") ;;
     *) [ -e "$CS/$f.o" ] || { echo "missing $CS/$f.o: run dynamicrafter_amd/csrc/build.sh first" >&2; exit 1; }
        OBJS+=("$CS/$f.o") ;;
   esac

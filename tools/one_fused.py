@@ -45,4 +45,11 @@ else:
     raise SystemExit(f"unknown kernel {which}")
 for _ in range(3): fn()
 torch.cuda.synchronize()
+if os.environ.get("ONE_TIME"):                  # HIP-event time of 20 launches (same-box A/B of tool builds through DC_HIP_LIB)
+    for rep in range(3):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(20): fn()
+        e1.record(); torch.cuda.synchronize()
+        print(f"{which} M={M} {os.environ.get('DC_HIP_LIB', 'product')}: {e0.elapsed_time(e1) / 20 * 1e3:8.1f} us", flush=True)
 print("done", which, M)
