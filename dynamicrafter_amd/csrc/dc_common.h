@@ -117,6 +117,9 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 // which kernel family dc_gemm_conv's dispatcher launched last on this host thread (profiling label; gemm_conv.hip)
 void dc_note_variant(const char* name);
 
+// gemm_conv_glds.hip: the current dc_gemm_set_plan value (kernel selection bits, include/dcrafter_hip.h)
+int dc_gemm_plan_now();
+
 // flash_pipe.hip: long self-attention (Lk % 64 == 0, Lk >= 256, no accumulate epilogue); called by dc_flash_attn_d64
 int dc_flash_pipe_launch(const bf16_t* q, const bf16_t* k, const bf16_t* v, bf16_t* o, int ldq, int ldk, int ldv, int ldo,
                          int batch, int heads, int Lq, int Lk, int64_t q_bstride, int64_t kv_bstride, float c,

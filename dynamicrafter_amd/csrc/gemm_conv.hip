@@ -310,6 +310,135 @@ int launch(const DcGemmParams& p, hipStream_t stream) {
     return DC_ERR_ARG;
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// 3x3 / stride 1 / pad 1 conv with a NARROW output (N <= 16): the UNet's conv_out (320 -> 4, openaimodel3d.py:545) and the
+// AutoencoderKL's decoder conv_out (128 -> 3, ae_modules.py:536). On the tile kernels N is padded to 64 columns (16x the MFMA
+// work) and the nine taps re-stage every activation row through the L2: 174 us for 189 MB of input at the 1024 config.
+// Here a workgroup owns NC_TH x NC_TW output pixels of one frame and walks the input in 64-channel slices: the slice of the
+// (NC_TH + 2) x (NC_TW + 2) halo window is staged ONCE in LDS (coalesced 128-byte rows, zeros outside the image) and the nine
+// taps read it at shifted pixel rows; v_mfma_f32_16x16x32_bf16 with the weights as the 16-row operand (rows >= N are zero
+// lanes, never loaded), so a lane ends up with 4 output channels of one pixel. The weight fragments of a slice (9 taps x 2 k
+// steps) live in registers, fetched straight from the packed weight (23 KB in all: cache-resident). HBM-bound by the input.
+constexpr int NC_TH = 4, NC_TW = 64;
+constexpr int NC_WIN_W = NC_TW + 2, NC_WIN = (NC_TH + 2) * NC_WIN_W;       // 396 window pixels
+constexpr int NC_LDS = NC_WIN * 128;                                       // one 64-channel slice: 128 B per pixel
+
+__device__ __forceinline__ int nc_off(int px, int chunk) { return px * 128 + ((chunk ^ (px & 7)) << 4); }
+
+template <bool F32>
+__global__ __launch_bounds__(256) void conv3x3_narrow_kernel(const DcGemmParams p, const int tiles_x, const int tiles_y) {
+    __shared__ __attribute__((aligned(16))) char win[NC_LDS];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lj = lane & 15, lq = lane >> 4;
+    const int per_frame = tiles_x * tiles_y;
+    const int frame = (int)blockIdx.x / per_frame;
+    const int trem = (int)blockIdx.x - frame * per_frame;
+    const int ty0 = (trem / tiles_x) * NC_TH, tx0 = (trem % tiles_x) * NC_TW;
+    const uint16_t* const fbase = p.A + (size_t)frame * p.IH * p.IW * p.lda;
+
+    f32x4_t acc[NC_TW / 16];
+#pragma unroll
+    for (int b = 0; b < NC_TW / 16; ++b) acc[b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    const int nslices = p.Cin / 64;
+    for (int sl = 0; sl < nslices; ++sl) {
+        // ---- weight fragments of the slice: lane (row lj, k quarter lq) holds k = 32 ks + 8 lq .. + 7 of (tap, ks)
+        bf16x8_t wf[9][2];
+        {
+            const uint16_t* wrow = p.W + (size_t)lj * p.K + (size_t)sl * 576 + lq * 8;
+#pragma unroll
+            for (int t = 0; t < 9; ++t)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    u32x4_t v = {0u, 0u, 0u, 0u};
+                    if (lj < p.N) v = *reinterpret_cast<const u32x4_t*>(wrow + t * 64 + ks * 32);
+                    wf[t][ks] = __builtin_bit_cast(bf16x8_t, v);
+                }
+        }
+        if (sl > 0) __syncthreads();                    // every wave is done reading the previous slice's window
+        // ---- the halo window of the slice: 8 threads per pixel (128 contiguous bytes), zeros outside the image
+        // (all loads of a thread first, unconditional - pixels outside the image read the zero page -, then the LDS stores)
+        constexpr int NC_IT = (NC_WIN * 8 + 255) / 256;
+        u32x4_t stg[NC_IT];
+#pragma unroll
+        for (int it = 0; it < NC_IT; ++it) {
+            int i = tid + it * 256;
+            if (i >= NC_WIN * 8) i = NC_WIN * 8 - 1;
+            const int px = i >> 3, ch = i & 7;
+            const int wy = px / NC_WIN_W, wx = px - wy * NC_WIN_W;
+            const int iy = ty0 + wy - 1, ix = tx0 + wx - 1;
+            const bool in = iy >= 0 && iy < p.IH && ix >= 0 && ix < p.IW;
+            const uint16_t* src = in ? fbase + ((size_t)iy * p.IW + ix) * p.lda + sl * 64 + ch * 8
+                                     : reinterpret_cast<const uint16_t*>(g_zero_chunk);
+            stg[it] = *reinterpret_cast<const u32x4_t*>(src);
+        }
+#pragma unroll
+        for (int it = 0; it < NC_IT; ++it) {
+            const int i = tid + it * 256;
+            if (i < NC_WIN * 8) *reinterpret_cast<u32x4_t*>(win + nc_off(i >> 3, i & 7)) = stg[it];
+        }
+        __syncthreads();
+        // ---- wave w = tile row w: 4 blocks of 16 pixels, 9 taps x 2 k steps each
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int dy = t / 3, dx = t - 3 * dy;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int b = 0; b < NC_TW / 16; ++b) {
+                    const int px = (wave + dy) * NC_WIN_W + 16 * b + lj + dx;
+                    const bf16x8_t xfrag = *reinterpret_cast<const bf16x8_t*>(win + nc_off(px, ks * 4 + lq));
+                    acc[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[t][ks], xfrag, acc[b], 0, 0, 0);
+                }
+        }
+    }
+    // ---- epilogue: lane (pixel lj of its block, channel quad lq) holds channels 4 lq .. 4 lq + 3
+    const int oy = ty0 + wave;
+    if (oy >= p.IH || 4 * lq >= p.N) return;
+    float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (p.bias) bv = *reinterpret_cast<const float4*>(p.bias + 4 * lq);
+#pragma unroll
+    for (int b = 0; b < NC_TW / 16; ++b) {
+        const int ox = tx0 + 16 * b + lj;
+        if (ox >= p.IW) continue;
+        const size_t row = ((size_t)frame * p.IH + oy) * p.IW + ox;
+        const float v0 = (acc[b][0] + bv.x) * p.alpha, v1 = (acc[b][1] + bv.y) * p.alpha;
+        const float v2 = (acc[b][2] + bv.z) * p.alpha, v3 = (acc[b][3] + bv.w) * p.alpha;
+        if constexpr (F32) {
+            *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.C) + row * p.ldc + 4 * lq) = make_float4(v0, v1, v2, v3);
+        } else {
+            uint2 pk;
+            pk.x = pack_bf2(v0, v1); pk.y = pack_bf2(v2, v3);
+            *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(p.C) + row * p.ldc + 4 * lq) = pk;
+        }
+    }
+}
+
+// the launches conv3x3_narrow_kernel takes: N a multiple of 4 (the bias / store quads), no epilogue extras
+inline bool narrow_conv_ok(const DcGemmParams& p) {
+    if ((dc_gemm_plan_now() & 128) || p.mode != 1 || p.N > 16 || p.N % 4 != 0 || p.stride != 1 || p.pad != 1 || p.ups) return false;
+    if (p.OH != p.IH || p.OW != p.IW || p.Cin % 64 != 0 || p.K != 9 * p.Cin) return false;
+    if (p.residual || p.rowvec || (p.flags & ~DC_GEMM_OUT_F32)) return false;
+    if (p.M % (p.IH * p.IW) != 0 || ((uintptr_t)p.A % 16) != 0 || ((uintptr_t)p.W % 16) != 0) return false;
+    if ((p.flags & DC_GEMM_OUT_F32) ? ((uintptr_t)p.C % 16 != 0) : (((uintptr_t)p.C % 8) != 0)) return false;
+    return true;
+}
+
+int launch_narrow_conv(const DcGemmParams& p, hipStream_t stream) {
+    const int tiles_x = (p.IW + NC_TW - 1) / NC_TW, tiles_y = (p.IH + NC_TH - 1) / NC_TH;
+    const long long grid = (long long)(p.M / (p.IH * p.IW)) * tiles_x * tiles_y;
+    if (grid <= 0 || grid > 0x7fffffffll) return DC_ERR_SHAPE;
+    dc_note_variant("conv3x3_narrow_kernel");
+    if (p.flags & DC_GEMM_OUT_F32)
+        hipLaunchKernelGGL(conv3x3_narrow_kernel<true>, dim3((unsigned)grid), dim3(256), 0, stream, p, tiles_x, tiles_y);
+    else
+        hipLaunchKernelGGL(conv3x3_narrow_kernel<false>, dim3((unsigned)grid), dim3(256), 0, stream, p, tiles_x, tiles_y);
+    DC_CHECK_LAUNCH();
+    return 0;
+}
+
 }  // namespace
 
 int dc_gemm_conv_glds_try(const DcGemmParams& p, hipStream_t stream);   // gemm_conv_glds.hip
@@ -344,6 +473,7 @@ extern "C" int dc_gemm_conv(const DcGemmParams* pp, void* stream_) {
     const bool geglu = (p.flags & DC_GEMM_GEGLU) != 0;
     if (geglu && ((p.N / 2) % 64 != 0 || p.n_pad < p.N)) return DC_ERR_SHAPE;
     if (p.n_pad < (p.N + 127) / 128 * 128) return DC_ERR_SHAPE;
+    if (narrow_conv_ok(p)) return launch_narrow_conv(p, stream);      // conv_out of the UNet / the AE decoder: N <= 16
     if (glds_enabled()) {                      // big launches: 256-row LDS-DMA pipeline
         const int r = dc_gemm_conv_glds_try(p, stream);
         if (r != -100) return r;

@@ -960,8 +960,9 @@ int launch_glds(const DcGemmParams& p, hipStream_t stream) {
 // >= 1024 tiles; bit 5 (32): without the K limit (tests, A/B).
 // bit 6 (64): the "whole waves + split remainder" plans as two launches (round 3's form) instead of one (GemmSplit::whole): tests, A/B.
 constexpr int PLAN_DEFAULT = 3 | 16;
-constexpr int PLAN_MASK = 3 | 16 | 32 | 64;
-inline bool plan_valid(int plan) { return plan >= 0 && plan <= 127 && !(plan & 4); }
+// bit 7 (128): conv3x3_narrow_kernel (gemm_conv.hip: conv_out of the UNet / AE decoder) off - the tile kernels take those launches.
+constexpr int PLAN_MASK = 3 | 16 | 32 | 64 | 128;
+inline bool plan_valid(int plan) { return plan >= 0 && plan <= 255 && !(plan & 4); }
 std::atomic<int> g_gemm_plan{[] {
     const char* e = getenv("DC_GEMM_PLAN");
     const int v = e ? atoi(e) : PLAN_DEFAULT;
@@ -1178,6 +1179,8 @@ int dc_gemm_conv_glds_try(const DcGemmParams& p, hipStream_t stream) {
     if (s128 > 0.f && waste128 <= 1.15f) return launch_glds_mode<128, 3>(p, stream);
     return -100;
 }
+
+int dc_gemm_plan_now() { return g_gemm_plan.load(std::memory_order_relaxed); }
 
 extern "C" int dc_gemm_set_plan(int plan) {
     if (!plan_valid(plan)) return DC_ERR_ARG;

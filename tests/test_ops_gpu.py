@@ -106,6 +106,38 @@ def test_conv3x3(ops, cfg):
     assert rel_l2(got, ref) < 4e-3
 
 
+# ---- conv_out of the UNet (320 -> 4, fp32 rows) and of the AE decoder (128 -> 3, bf16 rows, N padded to 4): the narrow-N kernel
+# (conv3x3_narrow_kernel: halo window of a 4 x 64 pixel tile in LDS, 16x16x32 MFMA) against torch and against the tile kernel
+@pytest.mark.parametrize("n,C,Co,H,W,f32", [
+    (4, 320, 4, 18, 32, True),        # whole tiles in y, half a tile in x
+    (3, 128, 3, 17, 70, False),       # ragged in both directions, 3 real channels of 4
+    (2, 64, 4, 8, 200, True),         # one slice, four tiles across
+    (5, 640, 8, 5, 9, False),         # tiny frames, two channel quads, ten slices
+])
+def test_conv3x3_narrow_out(ops, n, C, Co, H, W, f32):
+    x = bf(rnd(n, C, H, W, seed=1)); w = rnd(Co, C, 3, 3, seed=2, scale=(9 * C) ** -0.5); b = rnd(Co, seed=3)
+    ref = F.conv2d(x.float(), bf(w).float(), b, padding=1).permute(0, 2, 3, 1).reshape(-1, Co)
+    pw = ops.PackedWeight.conv3x3(w, b, DEV, n_align=4)
+    rows = x.permute(0, 2, 3, 1).reshape(-1, C).contiguous().to(DEV)
+    conv = dict(IH=H, IW=W, OH=H, OW=W, stride=1, pad=1, ups=0)
+    out = torch.full((n * H * W, pw.N), 7.0, dtype=torch.float32 if f32 else torch.bfloat16, device=DEV)
+    ops.gemm(rows, pw, out, conv=conv)
+    assert _variant(ops) == "conv3x3_narrow_kernel", _variant(ops)
+    assert rel_l2(out[:, :Co], ref) < (1e-5 if f32 else 4e-3)
+    if pw.N > Co:
+        assert out[:, Co:].abs().max().item() == 0          # the padding channel: zero weights and bias
+    lib = ops._hip.lib()
+    prev = lib.dc_gemm_set_plan(19 | 128)                   # plan bit 7: the tile kernels take the launch
+    assert prev >= 0
+    try:
+        out2 = torch.empty_like(out)
+        ops.gemm(rows, pw, out2, conv=conv)
+        assert _variant(ops) != "conv3x3_narrow_kernel", _variant(ops)
+    finally:
+        lib.dc_gemm_set_plan(prev)
+    assert rel_l2(out, out2) < (2e-6 if f32 else 4e-3)       # fp32 rows: the same bf16 products, another summation order
+
+
 def test_tconv3(ops):
     B, T, HW, Cc = 2, 5, 37, 128
     x = bf(rnd(B, Cc, T, HW, 1, seed=1)); w = rnd(Cc, Cc, 3, 1, 1, seed=2, scale=(3 * Cc) ** -0.5); b = rnd(Cc, seed=3)
