@@ -42,6 +42,42 @@ def test_cabi_argument_errors_without_gpu():
     assert lib.dc_temporal_attn_d64(C.c_void_p(8), 64, C.c_void_p(8), 64, 1, 17, 4, 1, 0.125, None) == -1
 
 
+def test_gemm_plan_validation_without_gpu():
+    """dc_gemm_set_plan: bits 0, 1, 4-7 are kernel-selection bits, bit 3 is accepted and dropped, bit 2 and values past 255 are
+    rejected; the call returns the previous plan (no GPU work)."""
+    from dynamicrafter_amd import _hip
+    lib = _hip.lib()
+    prev = lib.dc_gemm_set_plan(19)
+    assert prev >= 0
+    try:
+        assert lib.dc_gemm_set_plan(19 | 64 | 128) == 19
+        assert lib.dc_gemm_set_plan(11) == (19 | 64 | 128)          # bit 3 dropped on the way in
+        assert lib.dc_gemm_set_plan(4) == -2 and lib.dc_gemm_set_plan(256) == -2 and lib.dc_gemm_set_plan(-1) == -2
+        assert lib.dc_gemm_set_plan(0) == 3
+    finally:
+        lib.dc_gemm_set_plan(prev)
+
+
+@pytest.mark.skipif(not os.path.exists("/opt/rocm/bin/hipcc"), reason="needs hipcc")
+def test_ff_fused_isa_keeps_m0_for_the_lds_dma_only(tmp_path):
+    """The LDS-DMA pieces of ff_fused.hip write m0 without saving it (two scalar moves per piece are issue slots of a
+    one-wave-per-SIMD stream). That is only sound while nothing else in those kernels reads or writes m0: checked here in the
+    ISA hipcc emits for the product flags - every m0 reference must be an `s_mov_b32 m0, s..` of a piece, and every kernel
+    that issues global_load_lds must set m0 at least as often."""
+    cs = os.path.join(ROOT, "dynamicrafter_amd", "csrc")
+    out = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize",
+                          f"-I{os.path.join(ROOT, 'include')}", f"-I{cs}", "--cuda-device-only", "-S", "-o",
+                          str(tmp_path / "ff.s"), os.path.join(cs, "ff_fused.hip")], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    kernels = re.findall(r"^(_Z\S+):[^\n]*\n(.*?)\.Lfunc_end", open(tmp_path / "ff.s").read(), re.S | re.M)
+    assert len(kernels) >= 10
+    for name, body in kernels:
+        lines = [ln.strip() for ln in body.splitlines() if "m0" in ln and not ln.strip().startswith(";")]
+        other = [ln for ln in lines if not re.match(r"s_mov_b32 m0, s\d+", ln)]
+        assert not other, (name, other[:3])
+        assert len(lines) >= body.count("global_load_lds_dwordx4"), name
+
+
 def _tiny_model(config_name, extra=None):
     from dynamicrafter_amd.utils.utils import instantiate_from_config
     from tests.golden_cfg import TINY_AE, TINY_UNET
