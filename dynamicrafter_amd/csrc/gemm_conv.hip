@@ -416,6 +416,170 @@ __global__ __launch_bounds__(256) void conv3x3_narrow_kernel(const DcGemmParams 
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The same window design for N = 128 output channels: the AutoencoderKL's full-resolution ResnetBlock convs (ae_modules.py:151-210;
+// [2359296 x 128 x 1152] per 4 frames at 576 x 1024: nine launches per encode + decode call, 20 % of the AE). On the 256 x 128 tile
+// kernel the nine taps re-stage every input row through L2 -> LDS (5.4 GB per launch: the CUs' operand path, not the matrix pipe,
+// sets its 585 TFLOP/s). Here the halo window of a 4 x 64 pixel tile is staged once per 64-channel slice and the taps' weight
+// tiles (128 rows x 64 channels = 16 KB) follow through a second LDS buffer, fetched a tap ahead into registers; a wave owns
+// one tile row: 4 pixel blocks x 8 channel blocks of 16x16x32 accumulators (128 registers). Two workgroups per CU (66 KB each)
+// cover each other's barriers. Epilogue: + bias (+ residual), 8-byte stores of a lane's 4 channels.
+constexpr int WC_N = 128, WC_CB = WC_N / 16;
+constexpr int WC_WST = WC_N * 128;                                          // one tap of one slice: [128 rows][128 B]
+constexpr int WC_LDS = NC_LDS + WC_WST;
+
+__global__ __launch_bounds__(256, 2) void conv3x3_window128_kernel(const DcGemmParams p, const int tiles_x, const int tiles_y) {
+    extern __shared__ __attribute__((aligned(16))) char wsm[];
+    char* const win = wsm;
+    char* const wst = wsm + NC_LDS;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lj = lane & 15, lq = lane >> 4;
+    const int per_frame = tiles_x * tiles_y;
+    const int frame = (int)blockIdx.x / per_frame;
+    const int trem = (int)blockIdx.x - frame * per_frame;
+    const int ty0 = (trem / tiles_x) * NC_TH, tx0 = (trem % tiles_x) * NC_TW;
+    const uint16_t* const fbase = p.A + (size_t)frame * p.IH * p.IW * p.lda;
+
+    f32x4_t acc[NC_TW / 16][WC_CB];
+#pragma unroll
+    for (int b = 0; b < NC_TW / 16; ++b)
+#pragma unroll
+        for (int c = 0; c < WC_CB; ++c) acc[b][c] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    // a thread's share of a weight tap tile: 4 pieces of 16 bytes; piece i = tid + 256 i: row = i >> 3, chunk = i & 7
+    u32x4_t wreg[4];
+    auto w_fetch = [&](int sl, int t) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int pc = tid + 256 * i;
+            wreg[i] = *reinterpret_cast<const u32x4_t*>(p.W + (size_t)(pc >> 3) * p.K + (size_t)sl * 576 + t * 64 + (pc & 7) * 8);
+        }
+    };
+    auto w_store = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int pc = tid + 256 * i;
+            *reinterpret_cast<u32x4_t*>(wst + nc_off(pc >> 3, pc & 7)) = wreg[i];
+        }
+    };
+
+    const int nslices = p.Cin / 64;
+    w_fetch(0, 0);
+#pragma unroll 1
+    for (int sl = 0; sl < nslices; ++sl) {
+        if (sl > 0) __syncthreads();                    // every wave is done with the previous slice's window and last tap
+        {
+            // (in two batches: 13 staging registers at once do not fit beside the 128 accumulators at two waves per SIMD)
+            constexpr int NC_IT = (NC_WIN * 8 + 255) / 256, NC_H = (NC_IT + 1) / 2;
+#pragma unroll
+            for (int h0 = 0; h0 < NC_IT; h0 += NC_H) {
+                u32x4_t stg[NC_H];
+#pragma unroll
+                for (int it = 0; it < NC_H; ++it) {
+                    int i = tid + (h0 + it) * 256;
+                    if (i >= NC_WIN * 8) i = NC_WIN * 8 - 1;
+                    const int px = i >> 3, ch = i & 7;
+                    const int wy = px / NC_WIN_W, wx = px - wy * NC_WIN_W;
+                    const int iy = ty0 + wy - 1, ix = tx0 + wx - 1;
+                    const bool in = iy >= 0 && iy < p.IH && ix >= 0 && ix < p.IW;
+                    const uint16_t* src = in ? fbase + ((size_t)iy * p.IW + ix) * p.lda + sl * 64 + ch * 8
+                                             : reinterpret_cast<const uint16_t*>(g_zero_chunk);
+                    stg[it] = *reinterpret_cast<const u32x4_t*>(src);
+                }
+#pragma unroll
+                for (int it = 0; it < NC_H; ++it) {
+                    const int i = tid + (h0 + it) * 256;
+                    if (i < NC_WIN * 8) *reinterpret_cast<u32x4_t*>(win + nc_off(i >> 3, i & 7)) = stg[it];
+                }
+                asm volatile("" ::: "memory");
+            }
+        }
+        w_store();                                      // tap 0 of this slice (fetched during the previous slice's last tap)
+        __syncthreads();
+#pragma unroll 1
+        for (int t = 0; t < 9; ++t) {
+            // the next tap's weights (or the next slice's tap 0) on their way while this tap computes
+            if (t + 1 < 9) w_fetch(sl, t + 1);
+            else if (sl + 1 < nslices) w_fetch(sl + 1, 0);
+            const int dy = t / 3, dx = t - 3 * dy;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                bf16x8_t xb[NC_TW / 16];
+#pragma unroll
+                for (int b = 0; b < NC_TW / 16; ++b) {
+                    const int px = (wave + dy) * NC_WIN_W + 16 * b + lj + dx;
+                    xb[b] = *reinterpret_cast<const bf16x8_t*>(win + nc_off(px, ks * 4 + lq));
+                }
+#pragma unroll
+                for (int c = 0; c < WC_CB; ++c) {
+                    const bf16x8_t wa = *reinterpret_cast<const bf16x8_t*>(wst + nc_off(c * 16 + lj, ks * 4 + lq));
+#pragma unroll
+                    for (int b = 0; b < NC_TW / 16; ++b)
+                        acc[b][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa, xb[b], acc[b][c], 0, 0, 0);
+                }
+            }
+            if (t + 1 < 9) {
+                __syncthreads();                        // every wave has read this tap's weights
+                w_store();
+                __syncthreads();
+            }
+        }
+    }
+    // ---- epilogue: lane (pixel lj of block b, channel quad lq of block c) holds channels 16 c + 4 lq .. + 3
+    const int oy = ty0 + wave;
+    if (oy >= p.IH) return;
+    uint16_t* const cbase = reinterpret_cast<uint16_t*>(p.C);
+#pragma unroll
+    for (int b = 0; b < NC_TW / 16; ++b) {
+        const int ox = tx0 + 16 * b + lj;
+        if (ox >= p.IW) continue;
+        const size_t row = ((size_t)frame * p.IH + oy) * p.IW + ox;
+#pragma unroll
+        for (int c = 0; c < WC_CB; ++c) {
+            const int n = 16 * c + 4 * lq;
+            float4 v = make_float4(acc[b][c][0], acc[b][c][1], acc[b][c][2], acc[b][c][3]);
+            if (p.bias) {
+                const float4 bv = *reinterpret_cast<const float4*>(p.bias + n);
+                v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+            }
+            uint2 pk;
+            pk.x = pack_bf2(v.x, v.y); pk.y = pack_bf2(v.z, v.w);
+            if (p.residual) {                           // bf16(conv + bias) + residual, rounded again: the tile kernels' epilogue
+                const uint2 rr = *reinterpret_cast<const uint2*>(p.residual + row * p.ldr + n);
+                pk.x = pack_bf2(__uint_as_float(pk.x << 16) + __uint_as_float(rr.x << 16),
+                                __uint_as_float(pk.x & 0xffff0000u) + __uint_as_float(rr.x & 0xffff0000u));
+                pk.y = pack_bf2(__uint_as_float(pk.y << 16) + __uint_as_float(rr.y << 16),
+                                __uint_as_float(pk.y & 0xffff0000u) + __uint_as_float(rr.y & 0xffff0000u));
+            }
+            *reinterpret_cast<uint2*>(cbase + row * p.ldc + n) = pk;
+        }
+    }
+}
+
+inline bool window128_conv_ok(const DcGemmParams& p) {
+    if ((dc_gemm_plan_now() & 256) || p.mode != 1 || p.N != WC_N || p.stride != 1 || p.pad != 1 || p.ups) return false;
+    if (p.OH != p.IH || p.OW != p.IW || p.Cin % 64 != 0 || p.K != 9 * p.Cin || p.n_pad < WC_N) return false;
+    if (p.rowvec || p.flags || p.alpha != 1.0f) return false;
+    if (p.M % (p.IH * p.IW) != 0 || ((uintptr_t)p.A % 16) != 0 || ((uintptr_t)p.W % 16) != 0 || ((uintptr_t)p.C % 8) != 0) return false;
+    if (p.ldc % 4 != 0 || (p.residual && (p.ldr % 4 != 0 || ((uintptr_t)p.residual % 8) != 0))) return false;
+    // whole-chip launches only: below ~2 tiles per workgroup slot the tile kernels' finer split wins
+    const long long tiles = (long long)(p.M / (p.IH * p.IW)) * ((p.IW + NC_TW - 1) / NC_TW) * ((p.IH + NC_TH - 1) / NC_TH);
+    return tiles >= 1024;
+}
+
+int launch_window128_conv(const DcGemmParams& p, hipStream_t stream) {
+    static DcLdsOnce lds_once;
+    if (const int e = lds_once.ensure(reinterpret_cast<const void*>(&conv3x3_window128_kernel), WC_LDS)) return e;
+    const int tiles_x = (p.IW + NC_TW - 1) / NC_TW, tiles_y = (p.IH + NC_TH - 1) / NC_TH;
+    const long long grid = (long long)(p.M / (p.IH * p.IW)) * tiles_x * tiles_y;
+    if (grid <= 0 || grid > 0x7fffffffll) return DC_ERR_SHAPE;
+    dc_note_variant("conv3x3_window128_kernel");
+    hipLaunchKernelGGL(conv3x3_window128_kernel, dim3((unsigned)grid), dim3(256), WC_LDS, stream, p, tiles_x, tiles_y);
+    DC_CHECK_LAUNCH();
+    return 0;
+}
+
 // the launches conv3x3_narrow_kernel takes: N a multiple of 4 (the bias / store quads), no epilogue extras
 inline bool narrow_conv_ok(const DcGemmParams& p) {
     if ((dc_gemm_plan_now() & 128) || p.mode != 1 || p.N > 16 || p.N % 4 != 0 || p.stride != 1 || p.pad != 1 || p.ups) return false;
@@ -474,6 +638,7 @@ extern "C" int dc_gemm_conv(const DcGemmParams* pp, void* stream_) {
     if (geglu && ((p.N / 2) % 64 != 0 || p.n_pad < p.N)) return DC_ERR_SHAPE;
     if (p.n_pad < (p.N + 127) / 128 * 128) return DC_ERR_SHAPE;
     if (narrow_conv_ok(p)) return launch_narrow_conv(p, stream);      // conv_out of the UNet / the AE decoder: N <= 16
+    if (window128_conv_ok(p)) return launch_window128_conv(p, stream);    // the AE's full-resolution ResnetBlock convs: N = 128
     if (glds_enabled()) {                      // big launches: 256-row LDS-DMA pipeline
         const int r = dc_gemm_conv_glds_try(p, stream);
         if (r != -100) return r;

@@ -961,8 +961,9 @@ int launch_glds(const DcGemmParams& p, hipStream_t stream) {
 // bit 6 (64): the "whole waves + split remainder" plans as two launches (round 3's form) instead of one (GemmSplit::whole): tests, A/B.
 constexpr int PLAN_DEFAULT = 3 | 16;
 // bit 7 (128): conv3x3_narrow_kernel (gemm_conv.hip: conv_out of the UNet / AE decoder) off - the tile kernels take those launches.
-constexpr int PLAN_MASK = 3 | 16 | 32 | 64 | 128;
-inline bool plan_valid(int plan) { return plan >= 0 && plan <= 255 && !(plan & 4); }
+// bit 8 (256): conv3x3_window128_kernel (gemm_conv.hip: the AE's full-resolution N = 128 convs) off.
+constexpr int PLAN_MASK = 3 | 16 | 32 | 64 | 128 | 256;
+inline bool plan_valid(int plan) { return plan >= 0 && plan <= 511 && !(plan & 4); }
 std::atomic<int> g_gemm_plan{[] {
     const char* e = getenv("DC_GEMM_PLAN");
     const int v = e ? atoi(e) : PLAN_DEFAULT;

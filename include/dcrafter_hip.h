@@ -66,7 +66,8 @@ const char* dc_gemm_last_variant(void);
  * the two MFMA shapes of that kernel: plans 9 / 11 = 1 / 3); bit 2 is rejected (the 32x32x16 form and the LDS-window conv kernel
  * lost every measured shape and live in tools/experimental); bit 6 (64): the split-K plans "whole waves of tiles + the remainder
  * cut along K" as two launches instead of one (bit-identical results: tests, A/B); bit 7 (128): the narrow-output 3x3 conv kernel
- * (N <= 16: conv_out of the UNet and of the AE decoder) off, the tile kernels take those launches. All plans give the same results to bf16 rounding and each is
+ * (N <= 16: conv_out of the UNet and of the AE decoder) off, the tile kernels take those launches; bit 8 (256): likewise without the window kernel for N = 128 (the AE's
+ * full-resolution ResnetBlock convs). All plans give the same results to bf16 rounding and each is
  * bit-reproducible. Process-wide (env DC_GEMM_PLAN sets the initial value, validated the same way). Returns the previous plan,
  * or DC_ERR_ARG. */
 int dc_gemm_set_plan(int plan);

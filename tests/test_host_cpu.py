@@ -43,7 +43,7 @@ def test_cabi_argument_errors_without_gpu():
 
 
 def test_gemm_plan_validation_without_gpu():
-    """dc_gemm_set_plan: bits 0, 1, 4-7 are kernel-selection bits, bit 3 is accepted and dropped, bit 2 and values past 255 are
+    """dc_gemm_set_plan: bits 0, 1, 4-7 are kernel-selection bits, bit 3 is accepted and dropped, bit 2 and values past 511 are
     rejected; the call returns the previous plan (no GPU work)."""
     from dynamicrafter_amd import _hip
     lib = _hip.lib()
@@ -52,7 +52,7 @@ def test_gemm_plan_validation_without_gpu():
     try:
         assert lib.dc_gemm_set_plan(19 | 64 | 128) == 19
         assert lib.dc_gemm_set_plan(11) == (19 | 64 | 128)          # bit 3 dropped on the way in
-        assert lib.dc_gemm_set_plan(4) == -2 and lib.dc_gemm_set_plan(256) == -2 and lib.dc_gemm_set_plan(-1) == -2
+        assert lib.dc_gemm_set_plan(4) == -2 and lib.dc_gemm_set_plan(512) == -2 and lib.dc_gemm_set_plan(-1) == -2
         assert lib.dc_gemm_set_plan(0) == 3
     finally:
         lib.dc_gemm_set_plan(prev)

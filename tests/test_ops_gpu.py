@@ -138,6 +138,44 @@ def test_conv3x3_narrow_out(ops, n, C, Co, H, W, f32):
     assert rel_l2(out, out2) < (2e-6 if f32 else 4e-3)       # fp32 rows: the same bf16 products, another summation order
 
 
+# ---- the AE's full-resolution ResnetBlock convs (N = 128): conv3x3_window128_kernel (halo window + weight taps through LDS)
+@pytest.mark.parametrize("n,C,H,W,res", [
+    (16, 128, 64, 256, False),        # 1024 whole tiles
+    (18, 128, 61, 250, True),         # ragged in both directions, + residual (conv2 of a ResnetBlock)
+    (18, 256, 61, 250, False),        # four channel slices (the 256 -> 128 conv of decoder block 0)
+])
+def test_conv3x3_window128(ops, n, C, H, W, res):
+    Co = 128
+    g = torch.Generator(device=DEV).manual_seed(13)
+    x = torch.randn(n, C, H, W, device=DEV, generator=g).to(torch.bfloat16)
+    w = torch.randn(Co, C, 3, 3, device=DEV, generator=g) * (9 * C) ** -0.5
+    b = torch.randn(Co, device=DEV, generator=g)
+    r = torch.randn(n * H * W, Co, device=DEV, generator=g).to(torch.bfloat16) if res else None
+    ref = F.conv2d(x.float(), w.to(torch.bfloat16).float(), b, padding=1).permute(0, 2, 3, 1).reshape(-1, Co)
+    if res:
+        ref = ref.to(torch.bfloat16).float() + r.float()
+    pw = ops.PackedWeight.conv3x3(w.cpu(), b.cpu(), DEV)
+    rows = x.permute(0, 2, 3, 1).reshape(-1, C).contiguous()
+    conv = dict(IH=H, IW=W, OH=H, OW=W, stride=1, pad=1, ups=0)
+    out = torch.empty(n * H * W, Co, dtype=torch.bfloat16, device=DEV)
+    ops.gemm(rows, pw, out, conv=conv, residual=r)
+    assert _variant(ops) == "conv3x3_window128_kernel", _variant(ops)
+    assert rel_l2(out, ref) < 4e-3
+    out_b = torch.empty_like(out)
+    ops.gemm(rows, pw, out_b, conv=conv, residual=r)
+    assert torch.equal(out, out_b)                          # deterministic
+    lib = ops._hip.lib()
+    prev = lib.dc_gemm_set_plan(19 | 256)                   # plan bit 8: the tile kernel takes the launch
+    assert prev >= 0
+    try:
+        out2 = torch.empty_like(out)
+        ops.gemm(rows, pw, out2, conv=conv, residual=r)
+        assert _variant(ops) != "conv3x3_window128_kernel", _variant(ops)
+    finally:
+        lib.dc_gemm_set_plan(prev)
+    assert rel_l2(out, out2) < 4e-3
+
+
 def test_tconv3(ops):
     B, T, HW, Cc = 2, 5, 37, 128
     x = bf(rnd(B, Cc, T, HW, 1, seed=1)); w = rnd(Cc, Cc, 3, 1, 1, seed=2, scale=(3 * Cc) ** -0.5); b = rnd(Cc, seed=3)
