@@ -423,7 +423,7 @@ __global__ __launch_bounds__(256) void conv3x3_narrow_kernel(const DcGemmParams 
 // sets its 585 TFLOP/s). Here the halo window of a 4 x 64 pixel tile is staged once per 64-channel slice and the taps' weight
 // tiles (128 rows x 64 channels = 16 KB) follow through a second LDS buffer, fetched a tap ahead into registers; a wave owns
 // one tile row: 4 pixel blocks x 8 channel blocks of 16x16x32 accumulators (128 registers). Two workgroups per CU (66 KB each)
-// cover each other's barriers. Epilogue: + bias (+ residual), 8-byte stores of a lane's 4 channels.
+// cover each other's barriers. Epilogue: + bias, bf16 (+ residual), row-major 16-byte stores through the idle window buffer.
 constexpr int WC_N = 128, WC_CB = WC_N / 16;
 constexpr int WC_WST = WC_N * 128;                                          // one tap of one slice: [128 rows][128 B]
 constexpr int WC_LDS = NC_LDS + WC_WST;
@@ -526,33 +526,53 @@ __global__ __launch_bounds__(256, 2) void conv3x3_window128_kernel(const DcGemmP
             }
         }
     }
-    // ---- epilogue: lane (pixel lj of block b, channel quad lq of block c) holds channels 16 c + 4 lq .. + 3
+    // ---- epilogue: + bias, bf16, through the (now idle) window buffer into row-major order, 64 channels at a time: the wave's
+    // 64 pixels x 128 bytes in its private 8 KB region, read back as 8 pixels x 128 contiguous bytes per instruction (16 bytes
+    // per lane); the residual rows are fetched in the same pattern and added after the first rounding (the tile kernels' order)
+    __syncthreads();                                    // every wave is done with the window and the last tap
     const int oy = ty0 + wave;
     if (oy >= p.IH) return;
+    char* const patch = wsm + wave * 8192;
     uint16_t* const cbase = reinterpret_cast<uint16_t*>(p.C);
+    const int rpx = lane >> 3, rch = lane & 7;
+    const size_t row0 = ((size_t)frame * p.IH + oy) * p.IW + tx0;
 #pragma unroll
-    for (int b = 0; b < NC_TW / 16; ++b) {
-        const int ox = tx0 + 16 * b + lj;
-        if (ox >= p.IW) continue;
-        const size_t row = ((size_t)frame * p.IH + oy) * p.IW + ox;
+    for (int hf = 0; hf < 2; ++hf) {
+        u32x4_t rres[8];
+        if (p.residual) {
 #pragma unroll
-        for (int c = 0; c < WC_CB; ++c) {
-            const int n = 16 * c + 4 * lq;
-            float4 v = make_float4(acc[b][c][0], acc[b][c][1], acc[b][c][2], acc[b][c][3]);
-            if (p.bias) {
-                const float4 bv = *reinterpret_cast<const float4*>(p.bias + n);
-                v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+            for (int it = 0; it < 8; ++it) {
+                int px = it * 8 + rpx;
+                if (tx0 + px >= p.IW) px = 0;
+                rres[it] = *reinterpret_cast<const u32x4_t*>(p.residual + (row0 + px) * p.ldr + hf * 64 + rch * 8);
             }
-            uint2 pk;
-            pk.x = pack_bf2(v.x, v.y); pk.y = pack_bf2(v.z, v.w);
-            if (p.residual) {                           // bf16(conv + bias) + residual, rounded again: the tile kernels' epilogue
-                const uint2 rr = *reinterpret_cast<const uint2*>(p.residual + row * p.ldr + n);
-                pk.x = pack_bf2(__uint_as_float(pk.x << 16) + __uint_as_float(rr.x << 16),
-                                __uint_as_float(pk.x & 0xffff0000u) + __uint_as_float(rr.x & 0xffff0000u));
-                pk.y = pack_bf2(__uint_as_float(pk.y << 16) + __uint_as_float(rr.y << 16),
-                                __uint_as_float(pk.y & 0xffff0000u) + __uint_as_float(rr.y & 0xffff0000u));
+        }
+#pragma unroll
+        for (int b = 0; b < NC_TW / 16; ++b)
+#pragma unroll
+            for (int c4 = 0; c4 < 4; ++c4) {
+                const int c = hf * 4 + c4;
+                float4 v = make_float4(acc[b][c][0], acc[b][c][1], acc[b][c][2], acc[b][c][3]);
+                if (p.bias) {
+                    const float4 bv = *reinterpret_cast<const float4*>(p.bias + 16 * c + 4 * lq);
+                    v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+                }
+                uint2 pk;
+                pk.x = pack_bf2(v.x, v.y); pk.y = pack_bf2(v.z, v.w);
+                const int px = 16 * b + lj;                 // 8-byte slot (c4, lq) of the pixel's 128-byte row, chunk-swizzled
+                *reinterpret_cast<uint2*>(patch + nc_off(px, 2 * c4 + (lq >> 1)) + (lq & 1) * 8) = pk;
             }
-            *reinterpret_cast<uint2*>(cbase + row * p.ldc + n) = pk;
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int px = it * 8 + rpx;
+            u32x4_t d = *reinterpret_cast<const u32x4_t*>(patch + nc_off(px, rch));
+            if (p.residual) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    d[e] = pack_bf2(__uint_as_float(d[e] << 16) + __uint_as_float(rres[it][e] << 16),
+                                    __uint_as_float(d[e] & 0xffff0000u) + __uint_as_float(rres[it][e] & 0xffff0000u));
+            }
+            if (tx0 + px < p.IW) *reinterpret_cast<u32x4_t*>(cbase + (row0 + px) * p.ldc + hf * 64 + rch * 8) = d;
         }
     }
 }
@@ -562,7 +582,7 @@ inline bool window128_conv_ok(const DcGemmParams& p) {
     if (p.OH != p.IH || p.OW != p.IW || p.Cin % 64 != 0 || p.K != 9 * p.Cin || p.n_pad < WC_N) return false;
     if (p.rowvec || p.flags || p.alpha != 1.0f) return false;
     if (p.M % (p.IH * p.IW) != 0 || ((uintptr_t)p.A % 16) != 0 || ((uintptr_t)p.W % 16) != 0 || ((uintptr_t)p.C % 8) != 0) return false;
-    if (p.ldc % 4 != 0 || (p.residual && (p.ldr % 4 != 0 || ((uintptr_t)p.residual % 8) != 0))) return false;
+    if (p.ldc % 8 != 0 || ((uintptr_t)p.C % 16) != 0 || (p.residual && (p.ldr % 8 != 0 || ((uintptr_t)p.residual % 16) != 0))) return false;
     // whole-chip launches only: below ~2 tiles per workgroup slot the tile kernels' finer split wins
     const long long tiles = (long long)(p.M / (p.IH * p.IW)) * ((p.IW + NC_TW - 1) / NC_TW) * ((p.IH + NC_TH - 1) / NC_TH);
     return tiles >= 1024;
