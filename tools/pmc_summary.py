@@ -1,7 +1,7 @@
 """Summarise the counter CSVs written by tools/pmc_one_gemm.sh: python tools/pmc_summary.py gpurun_out/pmc_<name>"""
 import collections, csv, glob, os, sys
 d = sys.argv[1]
-KEYS = ("gemm", "flash", "gn_", "layernorm", "ff_geglu", "norm_linear", "ln_qkv", "cross_attn")
+KEYS = ("gemm", "flash", "gn_", "layernorm", "ff_geglu", "norm_linear", "ln_qkv", "cross_attn", "conv3x3_")
 for sub in sorted(os.listdir(d)):
     f = os.path.join(d, sub, "out_counter_collection.csv")
     if not os.path.exists(f):
