@@ -1009,13 +1009,13 @@ int launch_pipe_whole(const DcGemmParams& p, hipStream_t stream) {
 
 // 320-wide tiles with split-K: `full` leading tiles as whole tiles (0 = none), the remaining tiles cut into `splits`
 // K ranges + reduce. Partials: splits * (ntiles - full) * 256 * 320 floats of workspace.
-template <int MODE>
+template <int MODE, int BN = 320>
 int launch_glds320_split(const DcGemmParams& p, hipStream_t stream, int ntiles, int full, int splits, bool use_pipe, bool merged) {
-    constexpr int BN = 320, GSTAGES = 2;
+    constexpr int GSTAGES = 2;
     constexpr size_t lds = (size_t)GSTAGES * (GBM * GBK * 2 + BN * GBK * 2);
     static DcLdsOnce lds_once;
     if (const int e = lds_once.ensure(reinterpret_cast<const void*>(&gemm_conv_glds_kernel<BN, false, MODE, GSTAGES>), (int)lds)) return e;
-    {
+    if constexpr (BN == 320) {
         if (use_pipe) {
             dc_note_variant(MODE == 0 ? "gemm_pipe320x16_kernel+splitk" : MODE == 2 ? "gemm_pipe320x16_kernel<tconv>+splitk"
                             : MODE == 3 ? "gemm_pipe320x16_kernel<conv,ups>+splitk" : "gemm_pipe320x16_kernel<conv>+splitk");
@@ -1041,7 +1041,10 @@ int launch_glds320_split(const DcGemmParams& p, hipStream_t stream, int ntiles, 
             return 0;
         }
     }
-    dc_note_variant(MODE == 0 ? "gemm_conv_glds_kernel<320>+splitk" : MODE == 2 ? "gemm_conv_glds_kernel<320,tconv>+splitk" : "gemm_conv_glds_kernel<320,conv>+splitk");
+    if constexpr (BN == 320)
+        dc_note_variant(MODE == 0 ? "gemm_conv_glds_kernel<320>+splitk" : MODE == 2 ? "gemm_conv_glds_kernel<320,tconv>+splitk" : "gemm_conv_glds_kernel<320,conv>+splitk");
+    else
+        dc_note_variant(MODE == 0 ? "gemm_conv_glds_kernel<256>+splitk" : MODE == 2 ? "gemm_conv_glds_kernel<256,tconv>+splitk" : "gemm_conv_glds_kernel<256,conv>+splitk");
     GemmSplit sp;
     sp.err = nullptr; sp.whole = 0;
     if (full > 0) {
@@ -1168,6 +1171,24 @@ int dc_gemm_conv_glds_try(const DcGemmParams& p, hipStream_t stream) {
             if (p.mode == 1) return p.ups ? launch_glds320_split<3>(p, stream, w320, full, splits, use_pipe, merged)
                                           : launch_glds320_split<1>(p, stream, w320, full, splits, use_pipe, merged);
             return launch_glds320_split<2>(p, stream, w320, full, splits, use_pipe, merged);
+        }
+    }
+    // the same plan for the 256-wide tile (the AutoencoderKL's widths): its 72 x 128 level at 4 frames per call is 144 row tiles x 2 = 288
+    // tiles of 256 x 256 = 256 whole + 32 x 8 K ranges instead of 576 tiles of 256 x 128 in 2.25 rounds (DC_GEMM_SPLITK256=0: off)
+    static const int splitk256 = [] { const char* e = getenv("DC_GEMM_SPLITK256"); return e ? atoi(e) : 1; }();
+    if (splitk && splitk256 && force == 0 && !n320 && !out_f32 && p.workspace && p.N % 256 == 0 && p.n_pad >= p.N && (p.mode != 1 || !p.ups)) {
+        const int w256s = tiles_m * (p.N / 256), nk = p.K / GBK;
+        if (w256s > 256 && w256s <= 1280 && (w256s % 256) != 0 && (w256s % 256) <= 128) {
+            const int full = (w256s / 256) * 256;
+            int splits = 256 / (w256s - full);
+            if (splits > 8) splits = 8;
+            while (splits > 2 && nk / splits < 8) --splits;
+            const size_t need = (size_t)splits * (size_t)(w256s - full) * GBM * 256 * sizeof(float);
+            if (splits >= 2 && nk / splits >= 8 && need <= (size_t)p.workspace_bytes) {
+                if (p.mode == 0) return launch_glds320_split<0, 256>(p, stream, w256s, full, splits, false, false);
+                if (p.mode == 1) return launch_glds320_split<1, 256>(p, stream, w256s, full, splits, false, false);
+                return launch_glds320_split<2, 256>(p, stream, w256s, full, splits, false, false);
+            }
         }
     }
     if (force == 320 && n320) return use_pipe ? launch_pipe_whole(p, stream) : launch_glds_mode<320, 2>(p, stream);
