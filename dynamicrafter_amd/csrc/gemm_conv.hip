@@ -578,8 +578,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_window128_kernel(const DcGemmP
 }
 
 inline bool window128_conv_ok(const DcGemmParams& p) {
-    if ((dc_gemm_plan_now() & 256) || p.mode != 1 || p.N != WC_N || p.stride != 1 || p.pad != 1 || p.ups) return false;
-    if (p.OH != p.IH || p.OW != p.IW || p.Cin % 64 != 0 || p.K != 9 * p.Cin || p.n_pad < WC_N) return false;
+    // N = 256: two launches over the channel halves (the input is read twice; still ahead of the 256-wide tile kernel)
+    if ((dc_gemm_plan_now() & 256) || p.mode != 1 || (p.N != WC_N && p.N != 2 * WC_N) || p.stride != 1 || p.pad != 1 || p.ups) return false;
+    if (p.OH != p.IH || p.OW != p.IW || p.Cin % 64 != 0 || p.K != 9 * p.Cin || p.n_pad < p.N) return false;
     if (p.rowvec || p.flags || p.alpha != 1.0f) return false;
     if (p.M % (p.IH * p.IW) != 0 || ((uintptr_t)p.A % 16) != 0 || ((uintptr_t)p.W % 16) != 0 || ((uintptr_t)p.C % 8) != 0) return false;
     if (p.ldc % 8 != 0 || ((uintptr_t)p.C % 16) != 0 || (p.residual && (p.ldr % 8 != 0 || ((uintptr_t)p.residual % 16) != 0))) return false;
@@ -594,9 +595,17 @@ int launch_window128_conv(const DcGemmParams& p, hipStream_t stream) {
     const int tiles_x = (p.IW + NC_TW - 1) / NC_TW, tiles_y = (p.IH + NC_TH - 1) / NC_TH;
     const long long grid = (long long)(p.M / (p.IH * p.IW)) * tiles_x * tiles_y;
     if (grid <= 0 || grid > 0x7fffffffll) return DC_ERR_SHAPE;
-    dc_note_variant("conv3x3_window128_kernel");
-    hipLaunchKernelGGL(conv3x3_window128_kernel, dim3((unsigned)grid), dim3(256), WC_LDS, stream, p, tiles_x, tiles_y);
-    DC_CHECK_LAUNCH();
+    dc_note_variant(p.N == WC_N ? "conv3x3_window128_kernel" : "conv3x3_window128_kernel x2");
+    for (int h = 0; h < p.N / WC_N; ++h) {
+        DcGemmParams q = p;                             // channel half h: weight rows, bias, output and residual columns [128 h, 128 h + 128)
+        q.W = p.W + (size_t)h * WC_N * p.K;
+        if (p.bias) q.bias = p.bias + h * WC_N;
+        q.C = reinterpret_cast<uint16_t*>(p.C) + h * WC_N;
+        if (p.residual) q.residual = p.residual + h * WC_N;
+        q.N = WC_N;
+        hipLaunchKernelGGL(conv3x3_window128_kernel, dim3((unsigned)grid), dim3(256), WC_LDS, stream, q, tiles_x, tiles_y);
+        DC_CHECK_LAUNCH();
+    }
     return 0;
 }
 
