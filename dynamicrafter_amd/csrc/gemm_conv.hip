@@ -426,12 +426,15 @@ __global__ __launch_bounds__(256) void conv3x3_narrow_kernel(const DcGemmParams 
 // cover each other's barriers. Epilogue: + bias, bf16 (+ residual), row-major 16-byte stores through the idle window buffer.
 constexpr int WC_N = 128, WC_CB = WC_N / 16;
 constexpr int WC_WST = WC_N * 128;                                          // one tap of one slice: [128 rows][128 B]
-constexpr int WC_LDS = NC_LDS + WC_WST;
+constexpr int NC_GROUPS = (NC_WIN + 7) / 8;                                 // LDS-DMA pieces of 8 pixels (1 KB) per window slice
+constexpr int WC_WIN_BYTES = NC_GROUPS * 1024;                              // 50 KB + the tail of the last piece
+constexpr int WC_LDS = WC_WIN_BYTES + WC_WST;
 
 __global__ __launch_bounds__(256, 2) void conv3x3_window128_kernel(const DcGemmParams p, const int tiles_x, const int tiles_y) {
     extern __shared__ __attribute__((aligned(16))) char wsm[];
     char* const win = wsm;
-    char* const wst = wsm + NC_LDS;
+    char* const wst = wsm + WC_WIN_BYTES;
+    const unsigned lds_base = (unsigned)(uintptr_t)((const __attribute__((address_space(3))) char*)wsm);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lj = lane & 15, lq = lane >> 4;
@@ -469,33 +472,20 @@ __global__ __launch_bounds__(256, 2) void conv3x3_window128_kernel(const DcGemmP
 #pragma unroll 1
     for (int sl = 0; sl < nslices; ++sl) {
         if (sl > 0) __syncthreads();                    // every wave is done with the previous slice's window and last tap
-        {
-            // (in two batches: 13 staging registers at once do not fit beside the 128 accumulators at two waves per SIMD)
-            constexpr int NC_IT = (NC_WIN * 8 + 255) / 256, NC_H = (NC_IT + 1) / 2;
-#pragma unroll
-            for (int h0 = 0; h0 < NC_IT; h0 += NC_H) {
-                u32x4_t stg[NC_H];
-#pragma unroll
-                for (int it = 0; it < NC_H; ++it) {
-                    int i = tid + (h0 + it) * 256;
-                    if (i >= NC_WIN * 8) i = NC_WIN * 8 - 1;
-                    const int px = i >> 3, ch = i & 7;
-                    const int wy = px / NC_WIN_W, wx = px - wy * NC_WIN_W;
-                    const int iy = ty0 + wy - 1, ix = tx0 + wx - 1;
-                    const bool in = iy >= 0 && iy < p.IH && ix >= 0 && ix < p.IW;
-                    const uint16_t* src = in ? fbase + ((size_t)iy * p.IW + ix) * p.lda + sl * 64 + ch * 8
-                                             : reinterpret_cast<const uint16_t*>(g_zero_chunk);
-                    stg[it] = *reinterpret_cast<const u32x4_t*>(src);
-                }
-#pragma unroll
-                for (int it = 0; it < NC_H; ++it) {
-                    const int i = tid + (h0 + it) * 256;
-                    if (i < NC_WIN * 8) *reinterpret_cast<u32x4_t*>(win + nc_off(i >> 3, i & 7)) = stg[it];
-                }
-                asm volatile("" ::: "memory");
-            }
+        // the halo window by LDS-DMA: a wave instruction moves 8 pixels x 128 B (1 KB, lane-linear in LDS; the chunk swizzle is applied
+        // on the SOURCE side, pixels outside the image read the zero page) - no staging registers, all of a wave's 12-13 pieces in
+        // flight at once (through registers they went in two batches: 256 registers at two waves per SIMD leave no room for 13)
+        for (int g = wave; g < NC_GROUPS; g += 4) {
+            const int px = g * 8 + (lane >> 3), ch = (lane & 7) ^ (px & 7);
+            const int wy = px / NC_WIN_W, wx = px - wy * NC_WIN_W;
+            const int iy = ty0 + wy - 1, ix = tx0 + wx - 1;
+            const bool in = px < NC_WIN && iy >= 0 && iy < p.IH && ix >= 0 && ix < p.IW;
+            const uint16_t* src = in ? fbase + ((size_t)iy * p.IW + ix) * p.lda + sl * 64 + ch * 8
+                                     : reinterpret_cast<const uint16_t*>(g_zero_chunk);
+            asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(lds_base + g * 1024) : "memory");
         }
         w_store();                                      // tap 0 of this slice (fetched during the previous slice's last tap)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // this wave's window pieces have landed (hipcc does not count asm DMA)
         __syncthreads();
 #pragma unroll 1
         for (int t = 0; t < 9; ++t) {
