@@ -237,20 +237,20 @@ class LatentDiffusion(DDPM):
         else:
             k = max(1, self.ae_frames_per_call)
             fm = self.first_stage_model
+            # every call's launch sequence first (asynchronous; each posterior owns a copy of its moments) ...
+            posts = [fm.encode(x[i:i + k]) for i in range(0, x.shape[0], k)]
             noise_all = None
             if hasattr(fm, "latent_hw"):
-                # The posterior noise of every frame is drawn up front - one CPU draw per frame in frame order, exactly
+                # ... then the posterior noise of every frame, while the GPU works: one CPU draw per frame in frame order, exactly
                 # the draws the reference's per-frame posterior.sample() calls make (nothing else consumes the CPU
-                # generator in between) - and crosses to the device once: a host draw + blocking copy between the
+                # generator in between), crossing to the device once: a host draw + blocking copy between the
                 # launch sequences leaves the GPU idle for as long as the host takes (measured 76 -> 165 ms per clip on
-                # a busy box).
+                # a busy box; drawn ahead of the first launch it still cost the clip the draw's own time)
                 zh, zw = fm.latent_hw(x.shape[2], x.shape[3])
                 noise_all = torch.cat([torch.randn((1, fm.embed_dim, zh, zw)) for _ in range(x.shape[0])], dim=0)
                 noise_all = noise_all.to(x.device)
-            outs = []
-            for i in range(0, x.shape[0], k):
-                post = fm.encode(x[i:i + k])
-                outs.append(self.get_first_stage_encoding(post, noise=None if noise_all is None else noise_all[i:i + k]))
+            outs = [self.get_first_stage_encoding(post, noise=None if noise_all is None else noise_all[j * k:j * k + k])
+                    for j, post in enumerate(posts)]
             z = torch.cat(outs, dim=0)
         if five:
             z = z.reshape(b, t, *z.shape[1:]).permute(0, 2, 1, 3, 4).contiguous()
